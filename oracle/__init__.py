@@ -1,0 +1,174 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package;
+prefhetch_amd never does.  See the header of oracle/pf_oracle.c for what is restated and why
+parity is unpinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpf_oracle.so")
+
+# SEAL CoeffModulus::BFVDefault(N) primes (last prime of each set is the
+# key-switching "special prime").  Minimal primitive 2N-th roots from the same table.
+BFV_DEFAULT = {
+    1024: [0x7E00001],
+    2048: [0x3FFFFFFF000001],
+    4096: [0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001],
+    8192: [0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001, 0xFFFFFEBC001],
+    32768: [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0x7FFFFFFFBD0001, 0x7FFFFFFFBA0001, 0x7FFFFFFFAA0001,
+            0x7FFFFFFFA50001, 0x7FFFFFFF9F0001, 0x7FFFFFFF7E0001, 0x7FFFFFFF770001, 0x7FFFFFFF380001,
+            0x7FFFFFFF330001, 0x7FFFFFFF2D0001, 0x7FFFFFFF170001, 0x7FFFFFFF150001, 0x7FFFFFFEF00001,
+            0xFFFFFFFFF70001],
+}
+MIN_PSI = {
+    1024: [73993],
+    4096: [24250113, 29008497, 8625844],
+    8192: [1734247217, 304486499, 331339694, 9366611238, 632352760],
+    32768: [1155186985540, 631260524634, 1526647220035, 455957817523, 1650884166641, 10316746886,
+            768741990072, 3911086673862, 5947090524825, 47595902954, 2691682578057, 3903338373,
+            235185854118, 1769787302793, 3151164484090, 724233080554],
+}
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "pf_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libpf_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u64p, f32p, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_int64)
+        L.pfo_ctx_create.restype = C.c_void_p
+        L.pfo_ctx_create.argtypes = [C.c_uint32, C.c_uint32, u64p]
+        L.pfo_ctx_destroy.argtypes = [C.c_void_p]
+        L.pfo_ctx_psi.restype = C.c_uint64
+        L.pfo_ctx_psi.argtypes = [C.c_void_p, C.c_uint32]
+        L.pfo_min_primitive_root.argtypes = [C.c_uint64, C.c_uint64, u64p]
+        L.pfo_is_prime.argtypes = [C.c_uint64]
+        L.pfo_ntt_forward.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int]
+        L.pfo_ntt_inverse.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int]
+        L.pfo_dyadic_mul.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int]
+        L.pfo_poly_addsub.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int, C.c_int]
+        L.pfo_ct_pt_mul.argtypes = [C.c_void_p, u64p, u64p, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int]
+        L.pfo_precise_search.argtypes = [f32p, f32p, i64p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+        L.pfo_gather_rows.argtypes = [f32p, i64p, C.c_size_t, C.c_size_t, f32p]
+        L.pfo_flat_l2_search.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, f32p, i64p, C.c_int, C.c_int]
+        L.pfo_flat_l2_search_f32.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, f32p, i64p, C.c_int]
+        L.pfo_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+class Oracle:
+    """Oracle A context for ring degree N and a list of RNS moduli."""
+
+    ADD, SUB, NEG = 0, 1, 2
+    ACCUMULATE, IN_NTT, OUT_NTT = 1, 2, 4
+
+    def __init__(self, N, moduli):
+        self.N, self.moduli, self.L = int(N), [int(q) for q in moduli], len(moduli)
+        arr = np.array(self.moduli, dtype=np.uint64)
+        self._h = lib().pfo_ctx_create(self.N, self.L, _p(arr, C.c_uint64))
+        if not self._h:
+            raise ValueError("oracle: invalid N/moduli (need prime q < 2^61 with q = 1 mod 2N)")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().pfo_ctx_destroy(self._h)
+            self._h = None
+
+    def psi(self, l):
+        return int(lib().pfo_ctx_psi(self._h, l))
+
+    def _count(self, a):
+        assert a.size % self.N == 0
+        return a.size // self.N
+
+    def ntt_forward(self, polys, threads=0):
+        out = _u64(polys).copy()
+        lib().pfo_ntt_forward(self._h, _p(out, C.c_uint64), self._count(out), threads)
+        return out
+
+    def ntt_inverse(self, polys, threads=0):
+        out = _u64(polys).copy()
+        lib().pfo_ntt_inverse(self._h, _p(out, C.c_uint64), self._count(out), threads)
+        return out
+
+    def dyadic_mul(self, a, b, threads=0):
+        a, b = _u64(a), _u64(b)
+        out = np.empty_like(a)
+        lib().pfo_dyadic_mul(self._h, _p(a, C.c_uint64), _p(b, C.c_uint64), _p(out, C.c_uint64), self._count(a), threads)
+        return out
+
+    def addsub(self, a, b, op, threads=0):
+        a = _u64(a)
+        b = a if b is None else _u64(b)
+        out = np.empty_like(a)
+        lib().pfo_poly_addsub(self._h, _p(a, C.c_uint64), _p(b, C.c_uint64), _p(out, C.c_uint64), self._count(a), op, threads)
+        return out
+
+    def ct_pt_mul(self, ct, pt_ntt, flags=0, acc=None, threads=0):
+        """ct [B,2,L,N], pt_ntt [B,L,N] or [1,L,N]/[L,N] (broadcast)."""
+        ct, pt = _u64(ct), _u64(pt_ntt)
+        B = ct.size // (2 * self.L * self.N)
+        bcast = int(pt.size == self.L * self.N)
+        out = _u64(acc).copy() if (flags & self.ACCUMULATE) else np.empty_like(ct)
+        lib().pfo_ct_pt_mul(self._h, _p(ct, C.c_uint64), _p(pt, C.c_uint64), bcast, _p(out, C.c_uint64), B, flags, threads)
+        return out
+
+
+def precise_search(base, xq, ids):
+    base = np.ascontiguousarray(base, np.float32)
+    xq = np.ascontiguousarray(xq, np.float32)
+    ids = np.ascontiguousarray(ids, np.int64)
+    nq, c = ids.shape
+    out = np.empty((nq, c), np.float32)
+    lib().pfo_precise_search(_p(base, C.c_float), _p(xq, C.c_float), _p(ids, C.c_int64), nq, c, base.shape[1], _p(out, C.c_float))
+    return out
+
+
+def gather_rows(base, ids):
+    base = np.ascontiguousarray(base, np.float32)
+    ids = np.ascontiguousarray(ids, np.int64)
+    out = np.empty(ids.shape + (base.shape[1],), np.float32)
+    lib().pfo_gather_rows(_p(base, C.c_float), _p(ids, C.c_int64), ids.size, base.shape[1], _p(out, C.c_float))
+    return out
+
+
+def flat_l2_search(xb, xq, k, mode=0, threads=0, f32=False):
+    xb = np.ascontiguousarray(xb, np.float32)
+    xq = np.ascontiguousarray(xq, np.float32)
+    nq = xq.shape[0]
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    if f32:
+        lib().pfo_flat_l2_search_f32(_p(xb, C.c_float), xb.shape[0], xb.shape[1], _p(xq, C.c_float), nq, k, _p(D, C.c_float), _p(I, C.c_int64), threads)
+    else:
+        lib().pfo_flat_l2_search(_p(xb, C.c_float), xb.shape[0], xb.shape[1], _p(xq, C.c_float), nq, k, _p(D, C.c_float), _p(I, C.c_int64), mode, threads)
+    return D, I
+
+
+def max_threads():
+    return int(lib().pfo_max_threads())

@@ -1,0 +1,76 @@
+// sim_ntt.cpp -- host execution of the device NTT core (prefhetch_amd/csrc/ntt_core.hpp), one OS
+// thread per GPU lane, std::barrier for s_barrier.  TEST INFRASTRUCTURE: checks index maps, LDS
+// slot permutations and the FP64 error analysis bit-for-bit against the oracle without a GPU.
+// Build: g++ -std=c++20 -O2 -mfma -ffp-contract=off -pthread -shared -fPIC
+#include <barrier>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../prefhetch_amd/csrc/ntt_core.hpp"
+#include "../../prefhetch_amd/csrc/tables.hpp"
+
+using namespace pf;
+
+template <class G, class A, class Body>
+static void run_wg(Body &&body) {
+    std::vector<typename A::V> lds(G::N);
+    std::barrier bar(G::T);
+    std::vector<std::thread> th;
+    th.reserve(G::T);
+    for (int tid = 0; tid < G::T; ++tid)
+        th.emplace_back([&, tid] { auto sync = [&] { bar.arrive_and_wait(); }; body(lds.data(), tid, sync); });
+    for (auto &t : th) t.join();
+}
+
+template <int LOGN, class A>
+static void run_op(int op, int flags, const A &ar, const typename A::Tw *tw, const typename A::Tw *itw,
+                   const uint64_t *src, const uint64_t *pt, uint64_t *dst) {
+    using G = Geo<LOGN>;
+    run_wg<G, A>([&](typename A::V *lds, int tid, auto &sync) {
+        if (op == 0) body_ntt_fwd<G, A>(ar, tw, src, dst, lds, tid, sync);
+        else if (op == 1) body_ntt_inv<G, A>(ar, itw, src, dst, lds, tid, sync);
+        else {
+            switch (flags) {
+#define CASE(F) case F: body_ctpt<G, A, F>(ar, tw, itw, src, pt, dst, lds, tid, sync); break;
+                CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+#undef CASE
+            }
+        }
+    });
+}
+
+template <class A>
+static void dispatch(int logn, int op, int flags, const A &ar, const typename A::Tw *tw, const typename A::Tw *itw,
+                     const uint64_t *src, const uint64_t *pt, uint64_t *dst) {
+    switch (logn) {
+        case 10: run_op<10, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+        case 11: run_op<11, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+        case 12: run_op<12, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+        case 13: run_op<13, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+        case 14: run_op<14, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+    }
+}
+
+// op: 0 fwd, 1 inv, 2 ctpt(flags).  arith: 0 f64, 1 u64.  One limb-polynomial per call.
+extern "C" int pf_sim_run(int logn, uint64_t q, int arith, int op, int flags, const uint64_t *src,
+                          const uint64_t *pt, uint64_t *dst) {
+    LimbTables t;
+    std::string err;
+    if (logn < 10 || logn > 14) return -1;
+    if (!build_limb_tables(1u << logn, q, t, err)) return -2;
+    if (arith == 0) {
+        if (!t.f64_ok) return -3;
+        ArithF64 ar{(double)q, 1.0 / (double)q};
+        dispatch<ArithF64>(logn, op, flags, ar, t.fwd_f.data(), t.inv_f.data(), src, pt, dst);
+    } else {
+        ArithU64 ar{q, 2 * q, t.ratio0, t.ratio1};
+        dispatch<ArithU64>(logn, op, flags, ar, t.fwd_u.data(), t.inv_u.data(), src, pt, dst);
+    }
+    return 0;
+}
+
+extern "C" uint64_t pf_sim_psi(int logn, uint64_t q) {
+    LimbTables t; std::string err;
+    return build_limb_tables(1u << logn, q, t, err) ? t.psi : 0;
+}
