@@ -1,0 +1,120 @@
+/*
+ * prefhetch_hip.h -- C ABI of libprefhetch_hip.so: the MI355X (gfx950) implementation of the
+ * PreFHEtch server-side encrypted-query hot path.
+ *
+ * Drop-in boundary.  The reference's server (class Server, /root/reference/include/server/server_lib.h:12-50)
+ * reaches its numeric engines -- Microsoft SEAL and the PreFHEtch-faiss fork, both linked C++ libraries,
+ * /root/reference/CMakeLists.txt:22-38,62-68 -- by direct C++ calls.  This header is the FFI a maintainer
+ * binds instead (plain pointers and sizes, no C++/torch/HIP types); INTEGRATION.md shows the binding.
+ * Each entry point names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer (hipMalloc / pf_malloc / torch tensor data_ptr) on the
+ *     device the handle was created on, unless the parameter name ends in _host or says "host or device".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the device's null stream).  Calls enqueue work
+ *     and return; nothing synchronises unless documented.  Safe to capture into a hipGraph: no call
+ *     on the compute path allocates, frees or synchronises.
+ *   - RNS polynomial buffers: `n_limb_polys` polynomials of N uint64 coefficients, contiguous;
+ *     polynomial p belongs to RNS limb (p % L).  A SEAL Ciphertext's data() -- size x L x N,
+ *     poly-major, then limb, then coefficient -- and a batch of them therefore pass through unchanged.
+ *     Coefficients are canonical residues in [0, q_limb) on input and on output.
+ *   - Return value: PF_OK (0) or a negative pf_status; functions never throw and never abort.
+ *     pf_last_error() gives a thread-local human-readable detail string.
+ *   - Handles are not thread-safe individually; distinct handles may be used from distinct threads.
+ */
+#ifndef PREFHETCH_HIP_H
+#define PREFHETCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t pf_status;
+enum {
+    PF_OK = 0,
+    PF_ERR_INVALID_ARG = -1,
+    PF_ERR_UNSUPPORTED = -2,   /* parameter set outside what the kernels are built for */
+    PF_ERR_HIP = -3,           /* a HIP runtime call failed; see pf_last_error() */
+    PF_ERR_NO_DEVICE = -4,
+    PF_ERR_OOM = -5
+};
+
+typedef struct pf_ctx pf_ctx;     /* one RNS ring: N, L moduli, twiddle tables in HBM */
+typedef struct pf_flat pf_flat;   /* one brute-force L2 index: fp32 base matrix in HBM */
+typedef void *pf_stream;          /* hipStream_t */
+
+const char *pf_status_str(pf_status s);
+const char *pf_last_error(void);
+pf_status pf_device_count(int *count);
+
+/* ---- device memory helpers, so that a host written without HIP headers can own buffers ---------- */
+pf_status pf_malloc(int device, void **dptr, size_t bytes);
+pf_status pf_free(int device, void *dptr);
+pf_status pf_memcpy_h2d(int device, void *dst, const void *src_host, size_t bytes, pf_stream stream);
+pf_status pf_memcpy_d2h(int device, void *dst_host, const void *src, size_t bytes, pf_stream stream);
+pf_status pf_stream_synchronize(int device, pf_stream stream);
+
+/* ---- RNS ring context ------------------------------------------------------------------------- */
+/* Builds, per modulus: the minimal primitive 2N-th root psi, forward / inverse twiddle tables (with
+ * Shoup quotients, and FP64 images when q < 2^45), Barrett ratio floor(2^128/q); uploads them.
+ * Stands in for seal::SEALContext / util::NTTTables construction.  N in {1024,...,16384} (power of 2),
+ * every modulus prime, < 2^61, = 1 mod 2N.  Blocking (synchronises the upload). */
+pf_status pf_ctx_create(pf_ctx **ctx, int device, uint32_t N, uint32_t L, const uint64_t *moduli_host);
+pf_status pf_ctx_destroy(pf_ctx *ctx);
+/* arith_path_out[l]: 0 = exact-FP64 butterflies, 1 = 64-bit Shoup/Harvey butterflies.  Any out pointer may be NULL. */
+pf_status pf_ctx_info(const pf_ctx *ctx, uint32_t *N, uint32_t *L, uint64_t *moduli_out_host,
+                      uint64_t *psi_out_host, int32_t *arith_path_out_host);
+/* Testing hook: force every limb onto the 64-bit integer path (1) or restore automatic choice (0). */
+pf_status pf_ctx_force_u64(pf_ctx *ctx, int on);
+
+/* ---- polynomial arithmetic -------------------------------------------------------------------- */
+/* util::ntt_negacyclic_harvey: in-place forward negacyclic NTT, natural order in, bit-reversed out. */
+pf_status pf_ntt_forward(pf_ctx *ctx, uint64_t *polys, size_t n_limb_polys, pf_stream stream);
+/* util::inverse_ntt_negacyclic_harvey: in-place inverse, bit-reversed in, natural out, scaled by N^-1. */
+pf_status pf_ntt_inverse(pf_ctx *ctx, uint64_t *polys, size_t n_limb_polys, pf_stream stream);
+/* util::dyadic_product_coeffmod: out[i] = a[i]*b[i] mod q.  out may alias a or b. */
+pf_status pf_dyadic_mul(pf_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_limb_polys, pf_stream stream);
+/* util::add_poly_coeffmod / sub_poly_coeffmod / negate_poly_coeffmod (Evaluator::add_inplace etc.). */
+pf_status pf_poly_add(pf_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_limb_polys, pf_stream stream);
+pf_status pf_poly_sub(pf_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_limb_polys, pf_stream stream);
+pf_status pf_poly_negate(pf_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n_limb_polys, pf_stream stream);
+
+/* Evaluator::multiply_plain (+ transform_to_ntt / transform_from_ntt / add_inplace), fused:
+ *   ct      [B][2][L][N]   ciphertexts, coefficient form (or NTT form with PF_CTPT_IN_NTT)
+ *   pt_ntt  [pt_count][L][N] plaintexts already in NTT form; pt_count == B, or 1 to broadcast
+ *   out     [B][2][L][N]   product in coefficient form (or NTT form with PF_CTPT_OUT_NTT);
+ *                          with PF_CTPT_ACCUMULATE out += product (out must hold valid residues in
+ *                          the output domain).  out may alias ct.
+ * One launch; per (ciphertext, poly, limb): NTT -> dyadic -> inverse NTT without leaving the CU. */
+enum { PF_CTPT_ACCUMULATE = 1, PF_CTPT_IN_NTT = 2, PF_CTPT_OUT_NTT = 4 };
+pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, size_t pt_count,
+                       uint64_t *out, size_t B, int flags, pf_stream stream);
+
+/* ---- plaintext distance stages ---------------------------------------------------------------- */
+/* faiss::IndexFlatL2(d) + add(nb, xb): copies the base matrix [nb][d] fp32 (host or device pointer)
+ * into HBM and precomputes row norms.  Blocking. */
+pf_status pf_flat_create(pf_flat **idx, int device, const float *xb_host_or_device, size_t nb, uint32_t d);
+pf_status pf_flat_destroy(pf_flat *idx);
+pf_status pf_flat_info(const pf_flat *idx, size_t *nb, uint32_t *d);
+/* faiss::IndexFlatL2::search(nq, xq, k, D, I): squared L2, ascending; ties -> smaller id;
+ * entries beyond nb are (+inf, -1).  xq [nq][d], D [nq][k] fp32, I [nq][k] int64.  k <= 1024. */
+pf_status pf_flat_search(pf_flat *idx, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream);
+/* Server::preciseSearch (/root/reference/src/server/server_lib.cpp:140-167): D[i][j] = squared L2
+ * between xq[i] and base row ids[i][j], accumulated exactly as the reference does
+ * (float += pow(float diff, 2), i.e. through double per step).  ids [nq][c] int64, D [nq][c]. */
+pf_status pf_l2_gathered(pf_flat *idx, const float *xq, const int64_t *ids, size_t nq, uint32_t c, float *D, pf_stream stream);
+/* Server::preciseVectorPIR (server_lib.cpp:169-196) and Server::retrieve_centroids (:101-109):
+ * out[i] = base row ids[i].  ids [n_ids] int64, out [n_ids][d]. */
+pf_status pf_gather_rows(pf_flat *idx, const int64_t *ids, size_t n_ids, float *out, pf_stream stream);
+
+/* Bytes of scratch pf_flat_search needs for (nq, k); the library grows an internal workspace on
+ * first use (outside graph capture) -- call pf_flat_reserve up front to keep searches allocation-free. */
+pf_status pf_flat_reserve(pf_flat *idx, size_t nq_max, uint32_t k_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PREFHETCH_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libprefhetch_hip.so (the C ABI declared in include/prefhetch_hip.h).
+
+There is no fallback: if the HIP library is missing or does not load, importing fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprefhetch_hip.so")
+
+# every symbol include/prefhetch_hip.h declares
+SYMBOLS = [
+    "pf_status_str", "pf_last_error", "pf_device_count",
+    "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_stream_synchronize",
+    "pf_ctx_create", "pf_ctx_destroy", "pf_ctx_info", "pf_ctx_force_u64",
+    "pf_ntt_forward", "pf_ntt_inverse", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
+    "pf_ct_pt_mul",
+    "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
+    "pf_flat_reserve",
+]
+
+
+class PfError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__(f"{where}: status {status} ({detail})")
+        self.status = status
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"prefhetch_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C prefhetch_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    lib.pf_status_str.restype = C.c_char_p
+    lib.pf_status_str.argtypes = [C.c_int32]
+    lib.pf_last_error.restype = C.c_char_p
+    lib.pf_last_error.argtypes = []
+    lib.pf_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.pf_malloc.argtypes = [i32, C.POINTER(vp), sz]
+    lib.pf_free.argtypes = [i32, vp]
+    lib.pf_memcpy_h2d.argtypes = [i32, vp, vp, sz, vp]
+    lib.pf_memcpy_d2h.argtypes = [i32, vp, vp, sz, vp]
+    lib.pf_stream_synchronize.argtypes = [i32, vp]
+    lib.pf_ctx_create.argtypes = [C.POINTER(vp), i32, u32, u32, C.POINTER(C.c_uint64)]
+    lib.pf_ctx_destroy.argtypes = [vp]
+    lib.pf_ctx_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.pf_ctx_force_u64.argtypes = [vp, i32]
+    lib.pf_ntt_forward.argtypes = [vp, vp, sz, vp]
+    lib.pf_ntt_inverse.argtypes = [vp, vp, sz, vp]
+    for name in ("pf_dyadic_mul", "pf_poly_add", "pf_poly_sub"):
+        getattr(lib, name).argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.pf_poly_negate.argtypes = [vp, vp, vp, sz, vp]
+    lib.pf_ct_pt_mul.argtypes = [vp, vp, vp, sz, vp, sz, i32, vp]
+    lib.pf_flat_create.argtypes = [C.POINTER(vp), i32, vp, sz, u32]
+    lib.pf_flat_destroy.argtypes = [vp]
+    lib.pf_flat_info.argtypes = [vp, C.POINTER(sz), C.POINTER(u32)]
+    lib.pf_flat_search.argtypes = [vp, vp, sz, u32, vp, vp, vp]
+    lib.pf_l2_gathered.argtypes = [vp, vp, vp, sz, u32, vp, vp]
+    lib.pf_gather_rows.argtypes = [vp, vp, sz, vp, vp]
+    lib.pf_flat_reserve.argtypes = [vp, sz, u32]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        if name not in ("pf_status_str", "pf_last_error"):
+            fn.restype = C.c_int32
+    return lib
+
+
+lib = _load()
+
+
+def check(status, where):
+    if status != 0:
+        raise PfError(status, where, (lib.pf_last_error() or b"").decode() or lib.pf_status_str(status).decode())

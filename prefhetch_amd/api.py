@@ -1,0 +1,178 @@
+"""Host-side Python handles over the C ABI (torch supplies device memory and streams only).
+
+RnsContext  -- one RNS ring (N, moduli): NTT, dyadic product, add/sub/negate, fused ct x pt.
+               Stands in for the SEAL objects the reference links (CMakeLists.txt:33-38) at the
+               Evaluator::multiply_plain / transform_to_ntt / add_inplace level.
+FlatL2      -- faiss::IndexFlatL2 (reference include/server/server_lib.h:14) plus the gathered exact
+               distances of Server::preciseSearch and the row gather of preciseVectorPIR.
+
+uint64 residues travel in torch.int64 tensors (same bits); numpy uint64 <-> torch via .view(np.int64).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+ACCUMULATE, IN_NTT, OUT_NTT = 1, 2, 4
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("prefhetch_amd runs on a HIP device only (torch device type 'cuda'); there is no CPU path")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def _req(t, dtype, device_index, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == device_index and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous {dtype} tensor on cuda:{device_index}")
+    return C.c_void_p(t.data_ptr())
+
+
+def to_device_u64(a, device):
+    """numpy uint64 array -> torch.int64 tensor on `device` (bit-identical)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(device)
+
+
+def to_host_u64(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class RnsContext:
+    def __init__(self, N, moduli, device="cuda:0"):
+        self.device_index = _dev_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.N, self.moduli, self.L = int(N), [int(q) for q in moduli], len(moduli)
+        arr = (C.c_uint64 * self.L)(*self.moduli)
+        h = C.c_void_p()
+        check(lib.pf_ctx_create(C.byref(h), self.device_index, self.N, self.L, arr), "pf_ctx_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pf_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self):
+        psi = (C.c_uint64 * self.L)()
+        path = (C.c_int32 * self.L)()
+        check(lib.pf_ctx_info(self._h, None, None, None, psi, path), "pf_ctx_info")
+        return {"psi": list(psi), "arith_path": list(path)}
+
+    def force_u64(self, on=True):
+        check(lib.pf_ctx_force_u64(self._h, int(bool(on))), "pf_ctx_force_u64")
+
+    def _count(self, t):
+        if t.numel() % self.N:
+            raise ValueError("tensor size is not a multiple of N")
+        return t.numel() // self.N
+
+    def ntt_forward_(self, polys):
+        p = _req(polys, torch.int64, self.device_index, "polys")
+        check(lib.pf_ntt_forward(self._h, p, self._count(polys), _stream(self.device)), "pf_ntt_forward")
+        return polys
+
+    def ntt_inverse_(self, polys):
+        p = _req(polys, torch.int64, self.device_index, "polys")
+        check(lib.pf_ntt_inverse(self._h, p, self._count(polys), _stream(self.device)), "pf_ntt_inverse")
+        return polys
+
+    def _binary(self, fn, name, a, b, out):
+        out = torch.empty_like(a) if out is None else out
+        pa, pb, po = (_req(t, torch.int64, self.device_index, n) for t, n in ((a, "a"), (b, "b"), (out, "out")))
+        if a.numel() != b.numel() or a.numel() != out.numel():
+            raise ValueError("size mismatch")
+        check(fn(self._h, pa, pb, po, self._count(a), _stream(self.device)), name)
+        return out
+
+    def dyadic_mul(self, a, b, out=None):
+        return self._binary(lib.pf_dyadic_mul, "pf_dyadic_mul", a, b, out)
+
+    def add(self, a, b, out=None):
+        return self._binary(lib.pf_poly_add, "pf_poly_add", a, b, out)
+
+    def sub(self, a, b, out=None):
+        return self._binary(lib.pf_poly_sub, "pf_poly_sub", a, b, out)
+
+    def negate(self, a, out=None):
+        out = torch.empty_like(a) if out is None else out
+        pa, po = _req(a, torch.int64, self.device_index, "a"), _req(out, torch.int64, self.device_index, "out")
+        check(lib.pf_poly_negate(self._h, pa, po, self._count(a), _stream(self.device)), "pf_poly_negate")
+        return out
+
+    def ct_pt_mul(self, ct, pt_ntt, out=None, flags=0):
+        """ct [B,2,L,N]; pt_ntt [B,L,N] or [1,L,N] (broadcast); returns/accumulates into out [B,2,L,N]."""
+        per_ct = 2 * self.L * self.N
+        if ct.numel() % per_ct:
+            raise ValueError("ct size is not a multiple of 2*L*N")
+        B = ct.numel() // per_ct
+        pt_count = pt_ntt.numel() // (self.L * self.N)
+        if pt_ntt.numel() != pt_count * self.L * self.N or pt_count not in (1, B):
+            raise ValueError("pt_ntt must hold 1 or B plaintexts of L*N residues")
+        if out is None:
+            if flags & ACCUMULATE:
+                raise ValueError("ACCUMULATE needs an `out` operand")
+            out = torch.empty_like(ct)
+        pc, pp, po = (_req(t, torch.int64, self.device_index, n) for t, n in ((ct, "ct"), (pt_ntt, "pt_ntt"), (out, "out")))
+        check(lib.pf_ct_pt_mul(self._h, pc, pp, pt_count, po, B, int(flags), _stream(self.device)), "pf_ct_pt_mul")
+        return out
+
+
+class FlatL2:
+    def __init__(self, xb, device="cuda:0"):
+        """xb: [nb, d] float32 numpy array or torch tensor (host or device); copied into HBM."""
+        self.device_index = _dev_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        if isinstance(xb, np.ndarray):
+            xb = torch.from_numpy(np.ascontiguousarray(xb, dtype=np.float32))
+        if xb.dtype != torch.float32 or xb.dim() != 2:
+            raise ValueError("xb must be [nb, d] float32")
+        xb = xb.contiguous()
+        self.nb, self.d = int(xb.shape[0]), int(xb.shape[1])
+        h = C.c_void_p()
+        check(lib.pf_flat_create(C.byref(h), self.device_index, C.c_void_p(xb.data_ptr()), self.nb, self.d), "pf_flat_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pf_flat_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reserve(self, nq_max, k_max):
+        check(lib.pf_flat_reserve(self._h, nq_max, k_max), "pf_flat_reserve")
+
+    def search(self, xq, k):
+        pq = _req(xq, torch.float32, self.device_index, "xq")
+        if xq.dim() != 2 or xq.shape[1] != self.d:
+            raise ValueError("xq must be [nq, d]")
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        check(lib.pf_flat_search(self._h, pq, nq, k, C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()), _stream(self.device)), "pf_flat_search")
+        return D, I
+
+    def l2_gathered(self, xq, ids):
+        pq = _req(xq, torch.float32, self.device_index, "xq")
+        pi = _req(ids, torch.int64, self.device_index, "ids")
+        nq, c = ids.shape
+        if xq.shape != (nq, self.d):
+            raise ValueError("xq must be [nq, d] with nq = ids.shape[0]")
+        D = torch.empty((nq, c), dtype=torch.float32, device=self.device)
+        check(lib.pf_l2_gathered(self._h, pq, pi, nq, c, C.c_void_p(D.data_ptr()), _stream(self.device)), "pf_l2_gathered")
+        return D
+
+    def gather_rows(self, ids):
+        pi = _req(ids, torch.int64, self.device_index, "ids")
+        out = torch.empty(tuple(ids.shape) + (self.d,), dtype=torch.float32, device=self.device)
+        check(lib.pf_gather_rows(self._h, pi, ids.numel(), C.c_void_p(out.data_ptr()), _stream(self.device)), "pf_gather_rows")
+        return out

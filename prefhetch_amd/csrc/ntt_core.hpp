@@ -26,8 +26,11 @@
 
 #if defined(__HIPCC__)
 #define PF_HD __device__ __forceinline__
+// keeps hipcc's scheduler from hoisting the next phase's loads into this one (register budget)
+#define PF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define PF_HD inline
+#define PF_SCHED_FENCE() ((void)0)
 #endif
 
 namespace pf {
@@ -206,27 +209,27 @@ PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const typename A::Tw 
 template <class G, class A, int PASS>
 PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ itw, int tid) {
     constexpr int aa = G::a(PASS);
-    constexpr int kb_hi = G::bhi(PASS) - aa, kb_lo = G::blo(PASS) - aa;
+    constexpr int kb_lo = G::blo(PASS) - aa;
+    constexpr int kb_hi = G::bhi(PASS) - aa - (PASS == 0 ? 1 : 0);   // pass 0 ends with the N^-1 layer below
     const int high = PASS == 0 ? 0 : (tid >> aa);
 #pragma unroll
     for (int kb = kb_lo; kb <= kb_hi; ++kb) {
         const int m = 1 << (G::LOGN - 1 - (kb + aa));
-        if (PASS == 0 && kb == kb_hi) {                      // last layer: fold N^-1 in (SEAL does the same)
-            const typename A::Tw tn = itw[0], t = itw[1];
+        const typename A::Tw *__restrict__ tp = itw + m + (high << (G::LOGR - 1 - kb));
 #pragma unroll
-            for (int j = 0; j < (1 << kb); ++j) ar.inv_last(r[j], r[j | (1 << kb)], tn, t);
-        } else {
-            const typename A::Tw *__restrict__ tp = itw + m + (high << (G::LOGR - 1 - kb));
+        for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
+            const typename A::Tw t = tp[g];
 #pragma unroll
-            for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
-                const typename A::Tw t = tp[g];
-#pragma unroll
-                for (int j = 0; j < (1 << kb); ++j) {
-                    const int k0 = (g << (kb + 1)) | j, k1 = k0 | (1 << kb);
-                    ar.inv_bfly(r[k0], r[k1], t);
-                }
+            for (int j = 0; j < (1 << kb); ++j) {
+                const int k0 = (g << (kb + 1)) | j, k1 = k0 | (1 << kb);
+                ar.inv_bfly(r[k0], r[k1], t);
             }
         }
+    }
+    if constexpr (PASS == 0) {                               // last layer: fold N^-1 in (SEAL does the same)
+        const typename A::Tw tn = itw[0], t = itw[1];
+#pragma unroll
+        for (int j = 0; j < G::R / 2; ++j) ar.inv_last(r[j], r[j + G::R / 2], tn, t);
     }
 }
 
@@ -249,13 +252,21 @@ PF_HD void exchange(V (&r)[G::R], V *lds, int tid, Sync &&sync) {
 // ------------------------------------------------------------------------------------------------
 // Whole-transform drivers (registers hold layout 0 on entry of fwd, layout 0 on exit of inv)
 // ------------------------------------------------------------------------------------------------
+// forward passes [0, P-1) with their exchanges: leaves the registers in the layout of the last pass,
+// that pass still to run (callers may issue independent loads in between)
+template <class G, class A, class Sync>
+PF_HD void fwd_head(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
+                    typename A::V *lds, int tid, Sync &&sync) {
+    if constexpr (G::P >= 2) { fwd_pass<G, A, 0>(r, ar, tw, tid); exchange<G, typename A::V, 0, 1>(r, lds, tid, sync); }
+    if constexpr (G::P >= 3) { fwd_pass<G, A, 1>(r, ar, tw, tid); exchange<G, typename A::V, 1, 2>(r, lds, tid, sync); }
+    if constexpr (G::P >= 4) { fwd_pass<G, A, 2>(r, ar, tw, tid); exchange<G, typename A::V, 2, 3>(r, lds, tid, sync); }
+}
+
 template <class G, class A, class Sync>
 PF_HD void fwd_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
                    typename A::V *lds, int tid, Sync &&sync) {
-    fwd_pass<G, A, 0>(r, ar, tw, tid);
-    if constexpr (G::P >= 2) { exchange<G, typename A::V, 0, 1>(r, lds, tid, sync); fwd_pass<G, A, 1>(r, ar, tw, tid); }
-    if constexpr (G::P >= 3) { exchange<G, typename A::V, 1, 2>(r, lds, tid, sync); fwd_pass<G, A, 2>(r, ar, tw, tid); }
-    if constexpr (G::P >= 4) { exchange<G, typename A::V, 2, 3>(r, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, tw, tid); }
+    fwd_head<G, A>(r, ar, tw, lds, tid, sync);
+    fwd_pass<G, A, G::P - 1>(r, ar, tw, tid);
 }
 
 template <class G, class A, class Sync>
@@ -288,63 +299,67 @@ PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *
 enum : int { CTPT_ACCUMULATE = 1, CTPT_IN_NTT = 2, CTPT_OUT_NTT = 4 };
 
 template <class G, class A>
-PF_HD void load_l0(typename A::V (&r)[G::R], const uint64_t *__restrict__ src, int tid) {
+PF_HD void load_l0(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) r[k] = A::from_u64(src[(k << G::a(0)) | tid]);
+    for (int k = 0; k < G::R; ++k) r[k] = A::from_u64((src + (k << G::a(0)))[tid]);
 }
 
 // forward NTT of one limb-polynomial, in place or out of place
 template <class G, class A, class Sync>
-PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, const uint64_t *__restrict__ src,
-                        uint64_t *__restrict__ dst, typename A::V *lds, int tid, Sync &&sync) {
+PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, const uint64_t *src,
+                        uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0<G, A>(r, src, tid);
     fwd_all<G, A>(r, ar, tw, lds, tid, sync);
     if constexpr (G::P >= 2) exchange<G, typename A::V, G::P - 1, 0>(r, lds, tid, sync);
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) dst[(k << G::a(0)) | tid] = A::to_u64(ar.canon(r[k]));
+    for (int k = 0; k < G::R; ++k) (dst + (k << G::a(0)))[tid] = A::to_u64(ar.canon(r[k]));
 }
 
 template <class G, class A, class Sync>
-PF_HD void body_ntt_inv(const A &ar, const typename A::Tw *__restrict__ itw, const uint64_t *__restrict__ src,
-                        uint64_t *__restrict__ dst, typename A::V *lds, int tid, Sync &&sync) {
+PF_HD void body_ntt_inv(const A &ar, const typename A::Tw *__restrict__ itw, const uint64_t *src,
+                        uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0<G, A>(r, src, tid);
     if constexpr (G::P >= 2) exchange<G, typename A::V, 0, G::P - 1>(r, lds, tid, sync);
     inv_all<G, A>(r, ar, itw, lds, tid, sync);
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) dst[(k << G::a(0)) | tid] = A::to_u64(ar.canon_small(r[k]));
+    for (int k = 0; k < G::R; ++k) (dst + (k << G::a(0)))[tid] = A::to_u64(ar.canon_small(r[k]));
 }
 
 // ct x pt for one limb-polynomial: [NTT] -> dyadic with pt (NTT form) -> [INTT] -> [+= out]
 template <class G, class A, int FLAGS, class Sync>
 PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const typename A::Tw *__restrict__ itw,
-                     const uint64_t *__restrict__ ct, const uint64_t *__restrict__ pt, uint64_t *__restrict__ out,
+                     const uint64_t *ct, const uint64_t *pt, uint64_t *out,
                      typename A::V *lds, int tid, Sync &&sync) {
     using V = typename A::V;
     constexpr int LAST = G::P - 1;
     V r[G::R];
     load_l0<G, A>(r, ct, tid);
-    // the plaintext limb is fetched now (coalesced, layout 0) and consumed after the forward passes
     V pv[G::R];
-    load_l0<G, A>(pv, pt, tid);
     if constexpr (FLAGS & CTPT_IN_NTT) {
+        load_l0<G, A>(pv, pt, tid);
 #pragma unroll
         for (int k = 0; k < G::R; ++k) r[k] = ar.dyadic(r[k], pv[k]);
         if constexpr (FLAGS & CTPT_OUT_NTT) {
 #pragma unroll
             for (int k = 0; k < G::R; ++k) {
                 V v = ar.canon_small(r[k]);
-                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64(out[(k << G::a(0)) | tid])));
-                out[(k << G::a(0)) | tid] = A::to_u64(v);
+                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
+                (out + (k << G::a(0)))[tid] = A::to_u64(v);
             }
             return;
         }
         if constexpr (G::P >= 2) exchange<G, V, 0, LAST>(r, lds, tid, sync);
     } else {
         fwd_all<G, A>(r, ar, tw, lds, tid, sync);
-        // move the plaintext into the layout the forward transform ended in
+        // fetch the plaintext limb (coalesced, layout 0) and move it into the layout the forward
+        // transform ended in.  Issued here rather than earlier: together with a pass's hoisted
+        // twiddles 64 more live VGPRs spill at the 256-register budget of 2 workgroups per CU.
+        PF_SCHED_FENCE();
+        load_l0<G, A>(pv, pt, tid);
         if constexpr (G::P >= 2) exchange<G, V, 0, LAST>(pv, lds, tid, sync);
+        PF_SCHED_FENCE();
 #pragma unroll
         for (int k = 0; k < G::R; ++k) r[k] = ar.dyadic(ar.for_dyadic(r[k]), pv[k]);
         if constexpr (FLAGS & CTPT_OUT_NTT) {
@@ -352,8 +367,8 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
 #pragma unroll
             for (int k = 0; k < G::R; ++k) {
                 V v = ar.canon_small(r[k]);
-                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64(out[(k << G::a(0)) | tid])));
-                out[(k << G::a(0)) | tid] = A::to_u64(v);
+                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
+                (out + (k << G::a(0)))[tid] = A::to_u64(v);
             }
             return;
         }
@@ -362,8 +377,8 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
 #pragma unroll
     for (int k = 0; k < G::R; ++k) {
         V v = ar.canon_small(r[k]);
-        if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64(out[(k << G::a(0)) | tid])));
-        out[(k << G::a(0)) | tid] = A::to_u64(v);
+        if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
+        (out + (k << G::a(0)))[tid] = A::to_u64(v);
     }
 }
 

@@ -1,0 +1,413 @@
+// pf_flat.hip -- brute-force squared-L2 pre-filter (IndexFlatL2::search semantics), the gathered
+// exact distances of Server::preciseSearch and the row gather of Server::preciseVectorPIR /
+// retrieve_centroids.  gfx950 only.
+//
+// Reference call sites this stands in for:
+//   faiss::IndexFlatL2 m_Quantizer           /root/reference/include/server/server_lib.h:14, src/server/server_lib.cpp:33
+//   sort_nearest_centroids (executed L2 shortlist)  /root/reference/src/client/client_lib.cpp:50-81
+//   Server::preciseSearch                     /root/reference/src/server/server_lib.cpp:140-167
+//   Server::preciseVectorPIR / retrieve_centroids   server_lib.cpp:169-196 / 101-109
+//
+// Search = for each chunk of base rows: (1) k_l2_tile, an LDS-tiled fp32 distance tile kernel
+// (||x||^2 + ||y||^2 - 2 x.y, the decomposition faiss uses for nq >= 20, clamped at 0) on the f32
+// matrix pipe -- v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, so the result is
+// plain IEEE fp32 -- writing a [nq][chunk] slab that stays in the Infinity Cache; (2) k_select_chunk,
+// one workgroup per query keeping a reservoir (faiss ReservoirTopN does the same on the CPU for
+// k >= 100) of packed (distance bits, id) keys in LDS, compacted by a bitonic sort when it fills.
+// Keys order by (distance, id), which fixes the tie order faiss leaves undefined.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string>
+#include "pf_common.hpp"
+
+namespace pf {
+
+constexpr int TM = 128, TN = 128, TK = 32;      // distance tile: 128 queries x 128 base rows, K slabs of 32
+constexpr int LDA = TM + 1;                       // k-major LDS rows padded by one float: conflict-free transposing writes
+constexpr uint32_t SEL_CAP = 2048;                // reservoir capacity (keys); k <= SEL_CAP/2
+constexpr uint32_t SEL_THREADS = 256;
+constexpr uint64_t KEY_INF = 0x7F800000FFFFFFFFull;   // (+inf, id 2^32-1): sorts after every real key
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t id) { return ((uint64_t)__float_as_uint(d) << 32) | id; }
+
+// row norms, fp32 fma chain in index order
+__global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = x + i * d;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < d; ++k) acc = fmaf(r[k], r[k], acc);
+    out[i] = acc;
+}
+
+// One 128x128 tile of distances per workgroup (256 threads = 4 waves, each wave a 64x64 quadrant as
+// 2x2 MFMA 32x32 tiles).  Rows of the tile are queries, columns are base rows, so that a stored
+// accumulator register covers 32 consecutive floats of one query's slab row.
+struct TileArgs {
+    const float *xq; const float *xb; const float *qn; const float *bn;
+    float *slab;            // [nq][slab_ld]
+    uint32_t nq, d; size_t nb_first, nb_count; uint32_t slab_ld;
+};
+
+__device__ __forceinline__ void stage_slab(float *lds, const float *__restrict__ src, size_t row0, size_t rows_valid,
+                                           uint32_t d, uint32_t k0, int tid) {
+    // 128 rows x 32 k: thread t loads row (t>>3)+32*it, k4 = (t&7)*4; stores transposed lds[k][row]
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = (tid >> 3) + 32 * it;
+        const uint32_t k = k0 + (tid & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((size_t)row < rows_valid) {
+            const float *p = src + (row0 + row) * (size_t)d + k;
+            if (((d & 3) == 0) && k + 3 < d) v = *reinterpret_cast<const float4 *>(p);
+            else {
+                if (k < d) v.x = p[0];
+                if (k + 1 < d) v.y = p[1];
+                if (k + 2 < d) v.z = p[2];
+                if (k + 3 < d) v.w = p[3];
+            }
+        }
+        const int kk = (tid & 7) * 4;
+        lds[(kk + 0) * LDA + row] = v.x;
+        lds[(kk + 1) * LDA + row] = v.y;
+        lds[(kk + 2) * LDA + row] = v.z;
+        lds[(kk + 3) * LDA + row] = v.w;
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
+    __shared__ float sA[TK * LDA];
+    __shared__ float sB[TK * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t q0 = (size_t)blockIdx.y * TM;
+    const size_t c0 = (size_t)blockIdx.x * TN;                 // column inside the chunk
+    const size_t q_valid = p.nq - q0 < TM ? p.nq - q0 : TM;
+    const size_t c_valid = p.nb_count - c0 < TN ? p.nb_count - c0 : TN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
+        __syncthreads();
+        stage_slab(sA, p.xq, q0, q_valid, p.d, k0, tid);
+        stage_slab(sB, p.xb, p.nb_first + c0, c_valid, p.d, k0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < TK; ks += 2) {
+            const int k = ks + (lane >> 5);
+            const float a0 = sA[k * LDA + wm + (lane & 31)], a1 = sA[k * LDA + wm + 32 + (lane & 31)];
+            const float b0 = sB[k * LDA + wn + (lane & 31)], b1 = sB[k * LDA + wn + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const size_t col = c0 + wn + 32 * j + (lane & 31);
+        const bool col_ok = col < p.nb_count;
+        const float bnv = col_ok ? p.bn[p.nb_first + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t row = q0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (col_ok && row < p.nq) {
+                    float dist = fmaf(-2.f, acc[i][j][r], p.qn[row] + bnv);
+                    dist = dist < 0.f ? 0.f : dist;
+                    p.slab[row * p.slab_ld + col] = dist;
+                }
+            }
+        }
+    }
+}
+
+// ---- selection -----------------------------------------------------------------------------------
+struct SelArgs {
+    const float *slab; uint32_t slab_ld;
+    size_t nb_first, nb_count;      // ids of this chunk are nb_first + column
+    uint64_t *state;                // [nq][k] keys carried between chunks (ascending)
+    uint32_t *state_cnt;            // [nq]
+    uint32_t k;
+    int first, last;
+    float *D; int64_t *I;           // written when last
+};
+
+// in-LDS bitonic sort of SEL_CAP keys, ascending
+__device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid) {
+    for (uint32_t size = 2; size <= SEL_CAP; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < SEL_CAP / 2; t += SEL_THREADS) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(SEL_THREADS) k_select_chunk(SelArgs p) {
+    __shared__ uint64_t keys[SEL_CAP];
+    __shared__ uint32_t cnt;
+    __shared__ uint64_t tau;
+    const int tid = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const uint32_t k = p.k;
+    // load carried state
+    const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
+    for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = i < c0 ? p.state[q * k + i] : KEY_INF;
+    if (tid == 0) { cnt = c0; tau = c0 == k ? p.state[q * k + k - 1] : KEY_INF; }
+    __syncthreads();
+    const float *row = p.slab + q * (size_t)p.slab_ld;
+    // rounds of 4 columns per thread: at most 1024 new keys per round, so compact when fewer remain
+    for (size_t base = 0; base < p.nb_count; base += SEL_THREADS * 4) {
+        const uint32_t c = cnt;                               // stable here: a barrier separates it from every add
+        __syncthreads();                                      // ... and everyone has read it before the next add
+        if (c > SEL_CAP - SEL_THREADS * 4) {                  // workgroup-uniform
+            bitonic_sort(keys, tid);
+            if (tid == 0) { cnt = c < k ? c : k; tau = c >= k ? keys[k - 1] : KEY_INF; }
+            __syncthreads();
+            for (uint32_t i = cnt + tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = KEY_INF;
+            __syncthreads();
+        }
+        const uint64_t t = tau;
+        const size_t col = base + (size_t)tid * 4;
+        float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        if (col + 3 < p.nb_count && ((p.slab_ld & 3) == 0)) {
+            const float4 f = *reinterpret_cast<const float4 *>(row + col);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e < p.nb_count) {
+                const uint64_t key = make_key(v[e], (uint32_t)(p.nb_first + col + e));
+                if (key < t) { const uint32_t pos = atomicAdd(&cnt, 1u); keys[pos] = key; }
+            }
+        }
+        __syncthreads();
+    }
+    // end of chunk: sort, keep k, carry or emit
+    bitonic_sort(keys, tid);
+    const uint32_t total = cnt < k ? cnt : k;
+    if (p.last) {
+        for (uint32_t i = tid; i < k; i += SEL_THREADS) {
+            const uint64_t key = keys[i];
+            const bool ok = i < total;
+            p.D[q * k + i] = ok ? __uint_as_float((uint32_t)(key >> 32)) : INFINITY;
+            p.I[q * k + i] = ok ? (int64_t)(uint32_t)key : -1;
+        }
+    } else {
+        for (uint32_t i = tid; i < total; i += SEL_THREADS) p.state[q * k + i] = keys[i];
+        if (tid == 0) p.state_cnt[q] = total;
+    }
+}
+
+// ---- Server::preciseSearch: exact gathered distances ---------------------------------------------
+// float dist = 0; dist += std::pow(row[k] - q[k], 2)  ==  dist = (float)((double)dist + (double)diff*(double)diff)
+// with diff an fp32 subtraction (server_lib.cpp:151-162).  One lane per (query, candidate); the chain is
+// inherently sequential, the row read is 512 contiguous bytes per lane.
+__global__ void __launch_bounds__(256) k_l2_gathered(const float *__restrict__ xb, size_t nb, uint32_t d, const float *__restrict__ xq,
+                                                      const int64_t *__restrict__ ids, size_t nq, uint32_t c, float *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nq * c) return;
+    const size_t qi = t / c;
+    const int64_t id = ids[t];
+    if (id < 0 || (size_t)id >= nb) { out[t] = INFINITY; return; }
+    const float *row = xb + (size_t)id * d, *qv = xq + qi * d;
+    float dist = 0.f;
+    for (uint32_t k = 0; k < d; ++k) {
+        const float diff = row[k] - qv[k];
+        dist = (float)((double)dist + (double)diff * (double)diff);
+    }
+    out[t] = dist;
+}
+
+// out[i][:] = xb[ids[i]][:]; one wave per row, 16 B per lane where the row allows
+__global__ void __launch_bounds__(256) k_gather_rows(const float *__restrict__ xb, size_t nb, uint32_t d, const int64_t *__restrict__ ids,
+                                                      size_t n_ids, float *__restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t id = ids[r];
+    const bool ok = id >= 0 && (size_t)id < nb;
+    const float *src = xb + (ok ? (size_t)id : 0) * d;
+    float *dst = out + r * d;
+    if ((d & 3) == 0) {
+        for (uint32_t k = lane * 4; k < d; k += 256) {
+            float4 v = ok ? *reinterpret_cast<const float4 *>(src + k) : make_float4(NAN, NAN, NAN, NAN);
+            *reinterpret_cast<float4 *>(dst + k) = v;
+        }
+    } else {
+        for (uint32_t k = lane; k < d; k += 64) dst[k] = ok ? src[k] : NAN;
+    }
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+struct pf_flat {
+    int device = 0;
+    size_t nb = 0;
+    uint32_t d = 0;
+    float *xb = nullptr, *bn = nullptr;
+    // workspace (grown outside graph capture)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+struct WsPlan { size_t chunk, slab_ld, off_qn, off_state, off_cnt, off_slab, total; };
+
+WsPlan plan_ws(size_t nb, size_t nq, uint32_t k) {
+    WsPlan w{};
+    // slab of about 64 MiB (Infinity-Cache resident), a multiple of the tile width
+    size_t chunk = (64ull << 20) / (nq * 4);
+    chunk = chunk / 1024 * 1024;
+    if (chunk < 1024) chunk = 1024;
+    const size_t nb_pad = (nb + 127) / 128 * 128;
+    if (chunk > nb_pad) chunk = nb_pad;
+    w.chunk = chunk; w.slab_ld = chunk;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    w.off_qn = 0;
+    w.off_state = up(nq * 4);
+    w.off_cnt = w.off_state + up(nq * (size_t)k * 8);
+    w.off_slab = w.off_cnt + up(nq * 4);
+    w.total = w.off_slab + up(nq * chunk * 4);
+    return w;
+}
+
+pf_status ensure_ws(pf_flat *f, size_t bytes) {
+    if (bytes <= f->ws_bytes) return PF_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)cs;
+    if (f->ws) { PF_HIP(hipFree(f->ws)); f->ws = nullptr; f->ws_bytes = 0; }
+    PF_HIP(hipMalloc(&f->ws, bytes));
+    f->ws_bytes = bytes;
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+pf_status pf_flat_destroy(pf_flat *f) {
+    if (!f) return PF_OK;
+    {
+        DeviceGuard g(f->device);
+        if (f->xb) (void)hipFree(f->xb);
+        if (f->bn) (void)hipFree(f->bn);
+        if (f->ws) (void)hipFree(f->ws);
+    }
+    delete f;
+    return PF_OK;
+}
+
+pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, uint32_t d) {
+    if (!out || (!xb && nb) || d == 0) return fail(PF_ERR_INVALID_ARG, "null argument or d == 0");
+    *out = nullptr;
+    if (nb >= (1ull << 32) - 1) return fail(PF_ERR_UNSUPPORTED, "nb must be below 2^32-1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PF_ERR_NO_DEVICE, "no such HIP device");
+    PF_GUARD(device);
+    pf_flat *f = new pf_flat;
+    f->device = device; f->nb = nb; f->d = d;
+    const size_t bytes = (nb ? nb : 1) * (size_t)d * 4;
+    hipError_t e = hipMalloc((void **)&f->xb, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->bn, (nb ? nb : 1) * 4);
+    if (e == hipSuccess && nb) e = hipMemcpy(f->xb, xb, nb * (size_t)d * 4, hipMemcpyDefault);
+    if (e == hipSuccess && nb) {
+        hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
+    *out = f;
+    return PF_OK;
+}
+
+pf_status pf_flat_info(const pf_flat *f, size_t *nb, uint32_t *d) {
+    if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
+    if (nb) *nb = f->nb;
+    if (d) *d = f->d;
+    return PF_OK;
+}
+
+pf_status pf_flat_reserve(pf_flat *f, size_t nq_max, uint32_t k_max) {
+    if (!f || nq_max == 0 || k_max == 0) return fail(PF_ERR_INVALID_ARG, "bad argument");
+    PF_GUARD(f->device);
+    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max).total);
+}
+
+pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream) {
+    if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
+    if (nq == 0) return PF_OK;
+    if (!xq || !D || !I) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (k == 0 || k > SEL_CAP / 2) return fail(PF_ERR_UNSUPPORTED, "k must be in [1, 1024]");
+    if (nq > 0x7fffffffull / TM) return fail(PF_ERR_INVALID_ARG, "nq too large for one call");
+    PF_GUARD(f->device);
+    hipStream_t s = as_stream(stream);
+    const WsPlan w = plan_ws(f->nb, nq, k);
+    pf_status st = ensure_ws(f, w.total);
+    if (st != PF_OK) return st;
+    char *base = static_cast<char *>(f->ws);
+    float *qn = reinterpret_cast<float *>(base + w.off_qn);
+    uint64_t *state = reinterpret_cast<uint64_t *>(base + w.off_state);
+    uint32_t *scnt = reinterpret_cast<uint32_t *>(base + w.off_cnt);
+    float *slab = reinterpret_cast<float *>(base + w.off_slab);
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
+    const size_t n_chunks = f->nb ? (f->nb + w.chunk - 1) / w.chunk : 1;
+    for (size_t ci = 0; ci < n_chunks; ++ci) {
+        const size_t first = ci * w.chunk;
+        const size_t count = f->nb ? (f->nb - first < w.chunk ? f->nb - first : w.chunk) : 0;
+        if (count) {
+            TileArgs t{xq, f->xb, qn, f->bn, slab, (uint32_t)nq, f->d, first, count, (uint32_t)w.slab_ld};
+            const dim3 grid((unsigned)((count + TN - 1) / TN), (unsigned)((nq + TM - 1) / TM));
+            hipLaunchKernelGGL(k_l2_tile, grid, dim3(256), 0, s, t);
+        }
+        SelArgs a{slab, (uint32_t)w.slab_ld, first, count, state, scnt, k, ci == 0, ci + 1 == n_chunks, D, I};
+        hipLaunchKernelGGL(k_select_chunk, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status pf_l2_gathered(pf_flat *f, const float *xq, const int64_t *ids, size_t nq, uint32_t c, float *D, pf_stream stream) {
+    if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
+    if (nq == 0 || c == 0) return PF_OK;
+    if (!xq || !ids || !D) return fail(PF_ERR_INVALID_ARG, "null argument");
+    PF_GUARD(f->device);
+    const size_t total = nq * (size_t)c;
+    hipLaunchKernelGGL(k_l2_gathered, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), f->xb, f->nb, f->d, xq, ids, nq, c, D);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status pf_gather_rows(pf_flat *f, const int64_t *ids, size_t n_ids, float *out, pf_stream stream) {
+    if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
+    if (n_ids == 0) return PF_OK;
+    if (!ids || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    PF_GUARD(f->device);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n_ids + 3) / 4)), dim3(256), 0, as_stream(stream), f->xb, f->nb, f->d, ids, n_ids, out);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+}  // extern "C"

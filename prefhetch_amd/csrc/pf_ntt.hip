@@ -1,0 +1,233 @@
+// pf_ntt.hip -- RNS ring context, NTT / dyadic / add kernels and the fused ct x pt kernel behind the
+// C ABI of include/prefhetch_hip.h.  gfx950 only.  Kernel bodies live in ntt_core.hpp.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "pf_ntt_kernels.hpp"
+#include "pf_common.hpp"
+#include "tables.hpp"
+
+namespace pf {
+
+std::string &last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+struct pf_ctx {
+    int device = 0;
+    uint32_t N = 0, L = 0, logn = 0;
+    bool all_f64 = false, force_u64 = false;
+    std::vector<LimbTables> tabs;
+    LimbDev *d_limbs = nullptr;
+    void *d_tables = nullptr;       // all twiddle tables, 16-byte entries
+};
+
+namespace {
+
+// op: 0 forward, 1 inverse, 2 ctpt
+pf_status dispatch_logn(const pf_ctx *c, int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s) {
+    switch (c->logn) {
+        case 10: launch_logn_10(arith, op, flags, a, n, s); break;
+        case 11: launch_logn_11(arith, op, flags, a, n, s); break;
+        case 12: launch_logn_12(arith, op, flags, a, n, s); break;
+        case 13: launch_logn_13(arith, op, flags, a, n, s); break;
+        case 14: launch_logn_14(arith, op, flags, a, n, s); break;
+        default: return fail(PF_ERR_UNSUPPORTED, "ring degree not built (supported: 1024..16384)");
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status run_ntt_like(pf_ctx *c, int op, int flags, const NttArgs &a, size_t n, pf_stream stream) {
+    if (n == 0) return PF_OK;
+    if (n > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
+    PF_GUARD(c->device);
+    const int arith = (c->all_f64 && !c->force_u64) ? 0 : 1;
+    return dispatch_logn(c, arith, op, flags, a, n, as_stream(stream));
+}
+
+pf_status run_elementwise(pf_ctx *c, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream stream) {
+    if (!c || !a || !out || (op != EW_NEG && !b)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return PF_OK;
+    PF_GUARD(c->device);
+    const uint32_t chunk_log = c->logn < 11 ? c->logn : 11;
+    const size_t blocks = (n << c->logn) >> chunk_log;
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many coefficients for one launch");
+    EwArgs e{c->d_limbs, a, b ? b : a, out, c->L, c->logn};
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = as_stream(stream);
+    switch (op) {
+        case EW_MUL: hipLaunchKernelGGL((k_elementwise<EW_MUL>), grid, block, 0, s, e); break;
+        case EW_ADD: hipLaunchKernelGGL((k_elementwise<EW_ADD>), grid, block, 0, s, e); break;
+        case EW_SUB: hipLaunchKernelGGL((k_elementwise<EW_SUB>), grid, block, 0, s, e); break;
+        default: hipLaunchKernelGGL((k_elementwise<EW_NEG>), grid, block, 0, s, e); break;
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pf_status_str(pf_status s) {
+    switch (s) {
+        case PF_OK: return "ok";
+        case PF_ERR_INVALID_ARG: return "invalid argument";
+        case PF_ERR_UNSUPPORTED: return "unsupported parameters";
+        case PF_ERR_HIP: return "HIP runtime error";
+        case PF_ERR_NO_DEVICE: return "no usable device";
+        case PF_ERR_OOM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char *pf_last_error(void) { return last_error_ref().c_str(); }
+
+pf_status pf_device_count(int *count) {
+    if (!count) return fail(PF_ERR_INVALID_ARG, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return fail(PF_ERR_NO_DEVICE, "hipGetDeviceCount failed"); }
+    *count = n;
+    return PF_OK;
+}
+
+pf_status pf_malloc(int device, void **dptr, size_t bytes) {
+    if (!dptr) return fail(PF_ERR_INVALID_ARG, "null argument");
+    PF_GUARD(device);
+    PF_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return PF_OK;
+}
+pf_status pf_free(int device, void *dptr) {
+    PF_GUARD(device);
+    PF_HIP(hipFree(dptr));
+    return PF_OK;
+}
+pf_status pf_memcpy_h2d(int device, void *dst, const void *src_host, size_t bytes, pf_stream stream) {
+    PF_GUARD(device);
+    PF_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return PF_OK;
+}
+pf_status pf_memcpy_d2h(int device, void *dst_host, const void *src, size_t bytes, pf_stream stream) {
+    PF_GUARD(device);
+    PF_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return PF_OK;
+}
+pf_status pf_stream_synchronize(int device, pf_stream stream) {
+    PF_GUARD(device);
+    PF_HIP(hipStreamSynchronize(as_stream(stream)));
+    return PF_OK;
+}
+
+pf_status pf_ctx_destroy(pf_ctx *c) {
+    if (!c) return PF_OK;
+    {
+        DeviceGuard g(c->device);
+        if (c->d_tables) (void)hipFree(c->d_tables);
+        if (c->d_limbs) (void)hipFree(c->d_limbs);
+    }
+    delete c;
+    return PF_OK;
+}
+
+pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const uint64_t *moduli) {
+    if (!out || !moduli || L == 0) return fail(PF_ERR_INVALID_ARG, "null argument or L == 0");
+    *out = nullptr;
+    uint32_t logn = 0;
+    while ((1u << logn) < N) ++logn;
+    if ((1u << logn) != N || logn < 10 || logn > 14) return fail(PF_ERR_UNSUPPORTED, "N must be a power of two in [1024, 16384]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PF_ERR_NO_DEVICE, "no such HIP device");
+    PF_GUARD(device);
+    pf_ctx *c = new pf_ctx;
+    c->device = device; c->N = N; c->L = L; c->logn = logn;
+    c->tabs.resize(L);
+    c->all_f64 = true;
+    for (uint32_t l = 0; l < L; ++l) {
+        std::string err;
+        if (!build_limb_tables(N, moduli[l], c->tabs[l], err)) { delete c; return fail(PF_ERR_INVALID_ARG, "modulus " + std::to_string(l) + ": " + err); }
+        c->all_f64 = c->all_f64 && c->tabs[l].f64_ok;
+    }
+    std::vector<LimbDev> host(L);
+    static_assert(sizeof(TwU64) == 16 && sizeof(TwF64) == 16, "table entries are 16 bytes");
+    std::vector<TwU64> blob;                       // raw 16-byte entries; FP64 images are bit-copied in
+    auto append_u = [&](const std::vector<TwU64> &v) { const uint32_t off = (uint32_t)blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
+    auto append_f = [&](const std::vector<TwF64> &v) {
+        const uint32_t off = (uint32_t)blob.size();
+        for (const TwF64 &t : v) blob.push_back(TwU64{__builtin_bit_cast(uint64_t, t.w), __builtin_bit_cast(uint64_t, t.wq)});
+        return off;
+    };
+    for (uint32_t l = 0; l < L; ++l) {
+        const LimbTables &t = c->tabs[l];
+        LimbDev &d = host[l];
+        d = LimbDev{};
+        d.q = t.q; d.two_q = 2 * t.q; d.ratio0 = t.ratio0; d.ratio1 = t.ratio1;
+        d.qd = (double)t.q; d.qinv = 1.0 / (double)t.q;
+        d.fwd_u = append_u(t.fwd_u); d.inv_u = append_u(t.inv_u);
+        if (t.f64_ok) { d.fwd_f = append_f(t.fwd_f); d.inv_f = append_f(t.inv_f); }
+    }
+    if (hipMalloc(&c->d_tables, blob.size() * sizeof(TwU64)) != hipSuccess ||
+        hipMemcpy(c->d_tables, blob.data(), blob.size() * sizeof(TwU64), hipMemcpyHostToDevice) != hipSuccess) {
+        pf_ctx_destroy(c);
+        return fail(PF_ERR_HIP, "uploading twiddle tables failed");
+    }
+    if (hipMalloc((void **)&c->d_limbs, sizeof(LimbDev) * L) != hipSuccess ||
+        hipMemcpy(c->d_limbs, host.data(), sizeof(LimbDev) * L, hipMemcpyHostToDevice) != hipSuccess) {
+        pf_ctx_destroy(c);
+        return fail(PF_ERR_HIP, "uploading limb constants failed");
+    }
+    *out = c;
+    return PF_OK;
+}
+
+pf_status pf_ctx_info(const pf_ctx *c, uint32_t *N, uint32_t *L, uint64_t *moduli, uint64_t *psi, int32_t *path) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (N) *N = c->N;
+    if (L) *L = c->L;
+    for (uint32_t l = 0; l < c->L; ++l) {
+        if (moduli) moduli[l] = c->tabs[l].q;
+        if (psi) psi[l] = c->tabs[l].psi;
+        if (path) path[l] = (c->all_f64 && !c->force_u64) ? 0 : 1;
+    }
+    return PF_OK;
+}
+
+pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    c->force_u64 = on != 0;
+    return PF_OK;
+}
+
+pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
+    if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    return run_ntt_like(c, 0, 0, a, n, stream);
+}
+
+pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
+    if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    return run_ntt_like(c, 1, 0, a, n, stream);
+}
+
+pf_status pf_dyadic_mul(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_MUL, a, b, out, n, s); }
+pf_status pf_poly_add(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_ADD, a, b, out, n, s); }
+pf_status pf_poly_sub(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_SUB, a, b, out, n, s); }
+pf_status pf_poly_negate(pf_ctx *c, const uint64_t *a, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_NEG, a, nullptr, out, n, s); }
+
+pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, size_t pt_count, uint64_t *out, size_t B, int flags, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (B == 0) return PF_OK;
+    if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
+    if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, c->L, pt_count == 1 ? 1u : 0u};
+    return run_ntt_like(c, 2, flags, a, B * 2 * (size_t)c->L, stream);
+}
+
+}  // extern "C"

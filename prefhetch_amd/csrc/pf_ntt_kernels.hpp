@@ -1,0 +1,124 @@
+// pf_ntt_kernels.hpp -- gfx950 kernels wrapping the bodies of ntt_core.hpp, and their launch argument
+// blocks.  Included by pf_ntt_inst.hip (one translation unit per ring degree, so the degrees build
+// in parallel) and by pf_ntt.hip (element-wise kernels, context, C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ntt_core.hpp"
+
+namespace pf {
+
+// Per-limb constants in HBM; a workgroup reads its limb's entry through the scalar cache.
+// Twiddle tables are addressed as 16-byte-entry offsets from ONE kernel-argument base pointer, so the
+// loads are global_/s_load (a pointer fetched from memory would make them flat_load).
+struct LimbDev {
+    uint64_t q, two_q, ratio0, ratio1;
+    double qd, qinv;
+    uint32_t fwd_u, inv_u, fwd_f, inv_f;     // entry offsets into NttArgs::tables
+};
+
+struct NttArgs {
+    const LimbDev *limbs;
+    const void *tables;
+    const uint64_t *src;
+    uint64_t *dst;
+    const uint64_t *pt;
+    uint32_t L;
+    uint32_t pt_broadcast;
+};
+
+template <class A> struct ArithOf;
+template <> struct ArithOf<ArithF64> {
+    static __device__ __forceinline__ ArithF64 make(const LimbDev &l) { return ArithF64{l.qd, l.qinv}; }
+    static __device__ __forceinline__ const TwF64 *fwd(const void *t, const LimbDev &l) { return static_cast<const TwF64 *>(t) + l.fwd_f; }
+    static __device__ __forceinline__ const TwF64 *inv(const void *t, const LimbDev &l) { return static_cast<const TwF64 *>(t) + l.inv_f; }
+};
+template <> struct ArithOf<ArithU64> {
+    static __device__ __forceinline__ ArithU64 make(const LimbDev &l) { return ArithU64{l.q, l.two_q, l.ratio0, l.ratio1}; }
+    static __device__ __forceinline__ const TwU64 *fwd(const void *t, const LimbDev &l) { return static_cast<const TwU64 *>(t) + l.fwd_u; }
+    static __device__ __forceinline__ const TwU64 *inv(const void *t, const LimbDev &l) { return static_cast<const TwU64 *>(t) + l.inv_u; }
+};
+
+struct WgSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+
+// One workgroup = one limb-polynomial.  INVERSE selects the direction at compile time.
+template <int LOGN, class A, bool INVERSE>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ntt(NttArgs p) {
+    using G = Geo<LOGN>;
+    __shared__ typename A::V lds[G::N];
+    const size_t poly = blockIdx.x;
+    const LimbDev &lm = p.limbs[poly % p.L];
+    const A ar = ArithOf<A>::make(lm);
+    const uint64_t *src = p.src + poly * G::N;
+    uint64_t *dst = p.dst + poly * G::N;
+    if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+    else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+}
+
+// Fused ct x pt: block b handles limb-polynomial b of the ciphertext batch [B][2][L][N].
+template <int LOGN, class A, int FLAGS>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ctpt(NttArgs p) {
+    using G = Geo<LOGN>;
+    __shared__ typename A::V lds[G::N];
+    const size_t poly = blockIdx.x;
+    const uint32_t limb = (uint32_t)(poly % p.L);
+    const size_t ctidx = poly / (2 * (size_t)p.L);
+    const LimbDev &lm = p.limbs[limb];
+    const A ar = ArithOf<A>::make(lm);
+    const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
+    body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt, p.dst + poly * G::N,
+                           lds, (int)threadIdx.x, WgSync{});
+}
+
+// Element-wise kernels: 24 B (dyadic/add/sub) or 16 B (negate) of HBM traffic per coefficient, HBM-bound.
+// A block covers CHUNK consecutive coefficients of one limb-polynomial, 16 B per lane per access.
+enum EwOp : int { EW_MUL = 0, EW_ADD = 1, EW_SUB = 2, EW_NEG = 3 };
+
+struct EwArgs {
+    const LimbDev *limbs;
+    const uint64_t *a, *b;
+    uint64_t *out;
+    uint32_t L, logn;
+};
+
+template <int OP>
+__device__ __forceinline__ uint64_t ew_apply(const ArithU64 &ar, uint64_t x, uint64_t y) {
+    if constexpr (OP == EW_MUL) return ar.dyadic(x, y);
+    else if constexpr (OP == EW_ADD) { const uint64_t s = x + y; return s >= ar.q ? s - ar.q : s; }
+    else if constexpr (OP == EW_SUB) { return x >= y ? x - y : x + ar.q - y; }
+    else return x ? ar.q - x : 0;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_elementwise(EwArgs p) {
+    // chunk = 2048 coefficients (or N when N = 1024): 256 lanes x 16 B x 4 accesses
+    const uint32_t chunk_log = p.logn < 11 ? p.logn : 11;
+    const size_t first = (size_t)blockIdx.x << chunk_log;
+    const size_t poly = first >> p.logn;
+    const LimbDev &lm = p.limbs[poly % p.L];
+    const ArithU64 ar{lm.q, lm.two_q, lm.ratio0, lm.ratio1};
+    const uint32_t per_thread = (1u << chunk_log) / 512;      // 16-byte pairs per lane
+    const ulonglong2 *a2 = reinterpret_cast<const ulonglong2 *>(p.a + first);
+    const ulonglong2 *b2 = reinterpret_cast<const ulonglong2 *>(p.b + first);
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(p.out + first);
+    for (uint32_t j = 0; j < per_thread; ++j) {
+        const uint32_t i = j * 256 + threadIdx.x;
+        const ulonglong2 x = a2[i];
+        ulonglong2 y = x;
+        if constexpr (OP != EW_NEG) y = b2[i];
+        ulonglong2 r;
+        r.x = ew_apply<OP>(ar, x.x, y.x);
+        r.y = ew_apply<OP>(ar, x.y, y.y);
+        o2[i] = r;
+    }
+}
+
+}  // namespace pf
+
+
+namespace pf {
+// Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64;
+// op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`.
+#define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s);
+PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14)
+#undef PF_DECL_LAUNCH
+}  // namespace pf

@@ -1,0 +1,118 @@
+"""GPU parity tests for the plaintext distance stages: IndexFlatL2-style search (top-k indices bit-exact,
+fp32 distances within 1e-5 relative -- exact on SIFT-like integer data), Server::preciseSearch semantics
+(bit-exact, any data) and the row gather."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+RTOL = 1e-5   # north_star: fp32 distances within 1e-5 relative
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no silent CPU fallback)")
+    return "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import prefhetch_amd
+    return prefhetch_amd
+
+
+def _sift_like(rng, n, d=128):
+    return rng.integers(0, 256, (n, d)).astype(np.float32)
+
+
+@pytest.mark.parametrize("nb,nq,k", [(10000, 5, 100), (10000, 5, 200), (10000, 130, 20), (256, 5, 256), (1000, 1, 1),
+                                      (33000, 257, 200), (100, 3, 200), (4097, 7, 1024)])
+def test_flat_search_integer_data_exact(pf, nb, nq, k):
+    rng = np.random.default_rng(nb + nq + k)
+    xb, xq = _sift_like(rng, nb), _sift_like(rng, nq)
+    xb[nb // 2] = xb[0]                                    # exact duplicate rows: tie -> smaller id first
+    idx = pf.FlatL2(xb, _dev())
+    D, I = idx.search(torch.from_numpy(xq).to(_dev()), k)
+    Dr, Ir = oracle.flat_l2_search(xb, xq, k)
+    assert (I.cpu().numpy() == Ir).all()
+    assert (D.cpu().numpy() == Dr).all()
+
+
+def test_flat_search_gaussian_tolerance(pf):
+    rng = np.random.default_rng(4)
+    nb, nq, k, d = 20000, 64, 100, 128
+    xb, xq = rng.standard_normal((nb, d)).astype(np.float32), rng.standard_normal((nq, d)).astype(np.float32)
+    idx = pf.FlatL2(xb, _dev())
+    D, I = idx.search(torch.from_numpy(xq).to(_dev()), k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    exact = ((xb[None].astype(np.float64) - xq[:, None].astype(np.float64)) ** 2).sum(-1)     # [nq][nb]
+    assert (np.diff(D, axis=1) >= 0).all()
+    for i in range(nq):
+        di = exact[i][I[i]]
+        assert np.allclose(D[i], di, rtol=RTOL, atol=0)
+        kth = np.sort(exact[i])[k - 1]
+        assert (di <= kth * (1 + 4 * RTOL)).all()           # tie-tolerant: every returned id is a true top-k within tolerance
+        assert len(set(I[i])) == k
+
+
+def test_flat_search_odd_dimension(pf):
+    rng = np.random.default_rng(6)
+    xb, xq = _sift_like(rng, 3000, 30), _sift_like(rng, 9, 30)
+    idx = pf.FlatL2(xb, _dev())
+    D, I = idx.search(torch.from_numpy(xq).to(_dev()), 10)
+    Dr, Ir = oracle.flat_l2_search(xb, xq, 10)
+    assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
+
+
+def test_centroid_shortlist_matches_client(pf):
+    """sort_nearest_centroids (client_lib.cpp:50-81) on the reference shapes: NQUERY=5, NLIST=256, NPROBE=20."""
+    rng = np.random.default_rng(8)
+    cent, xq = _sift_like(rng, 256), _sift_like(rng, 5)
+    idx = pf.FlatL2(cent, _dev())
+    D, I = idx.search(torch.from_numpy(xq).to(_dev()), 20)
+    Dr, Ir = oracle.flat_l2_search(cent, xq, 20, mode=1)
+    assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
+
+
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_precise_search_bit_exact(pf, gaussian):
+    """Server::preciseSearch (server_lib.cpp:140-167) on the reference shapes NBASE=10000, NQUERY=5, COARSE_PROBE=200."""
+    rng = np.random.default_rng(10 + gaussian)
+    if gaussian:
+        base, xq = rng.standard_normal((10000, 128)).astype(np.float32), rng.standard_normal((5, 128)).astype(np.float32)
+    else:
+        base, xq = _sift_like(rng, 10000), _sift_like(rng, 5)
+    ids = rng.integers(0, 10000, (5, 200)).astype(np.int64)
+    idx = pf.FlatL2(base, _dev())
+    got = idx.l2_gathered(torch.from_numpy(xq).to(_dev()), torch.from_numpy(ids).to(_dev())).cpu().numpy()
+    assert (got == oracle.precise_search(base, xq, ids)).all()
+
+
+def test_gather_rows(pf):
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal((10000, 128)).astype(np.float32)
+    ids = rng.integers(0, 10000, (5, 100)).astype(np.int64)
+    idx = pf.FlatL2(base, _dev())
+    got = idx.gather_rows(torch.from_numpy(ids).to(_dev())).cpu().numpy()
+    assert (got == oracle.gather_rows(base, ids)).all()
+
+
+def test_config3_prefilter_full_size(pf):
+    """BASELINE config 3 pre-filter: 1M x 128 base, 1024 queries, k=200.  A 16-query slice against the oracle;
+    all queries through properties (sorted, unique, distances equal to recomputed exact distances)."""
+    rng = np.random.default_rng(20250801 + 3)
+    nb, nq, k = 1_000_000, 1024, 200
+    xb = rng.integers(0, 256, (nb, 128), dtype=np.uint8).astype(np.float32)
+    xq = rng.integers(0, 256, (nq, 128), dtype=np.uint8).astype(np.float32)
+    idx = pf.FlatL2(xb, _dev())
+    dq = torch.from_numpy(xq).to(_dev())
+    D, I = idx.search(dq, k)
+    assert bool((D[:, 1:] >= D[:, :-1]).all())
+    exact = idx.l2_gathered(dq, I)                          # exact on integer data, any summation order
+    assert torch.equal(exact, D)
+    assert all(len(set(r)) == k for r in I[:64].cpu().numpy())
+    Dr, Ir = oracle.flat_l2_search(xb, xq[500:516], k)
+    assert (I[500:516].cpu().numpy() == Ir).all() and (D[500:516].cpu().numpy() == Dr).all()

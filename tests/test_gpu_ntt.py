@@ -1,0 +1,190 @@
+"""GPU parity tests (run on MI355X with -m gpu): HIP kernels called through the C ABI against the CPU
+oracle on the same seeded inputs -- bit-exact, since this is integer modular arithmetic."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import edge_poly
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no silent CPU fallback)")
+    return "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import prefhetch_amd
+    return prefhetch_amd
+
+
+def _ctx(pf, N, qs, force_u64=False):
+    c = pf.RnsContext(N, qs, _dev())
+    if force_u64:
+        c.force_u64(True)
+    return c
+
+
+CONFIGS = [  # (N, moduli, force_u64)
+    (1024, oracle.BFV_DEFAULT[1024], False),
+    (1024, oracle.BFV_DEFAULT[1024], True),
+    (2048, oracle.BFV_DEFAULT[2048], False),              # 54-bit prime -> u64 path automatically
+    (4096, oracle.BFV_DEFAULT[4096][:2], False),
+    (4096, oracle.BFV_DEFAULT[4096], True),
+    (8192, oracle.BFV_DEFAULT[8192][:4], False),
+    (8192, oracle.BFV_DEFAULT[8192], True),
+    (8192, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001], False),   # 55-bit primes at N=8192 -> u64 path
+    (16384, [0x7FFFFFFFE90001, 0xFFFFFEBC001], False),
+]
+
+
+@pytest.mark.parametrize("N,qs,force", CONFIGS)
+def test_ntt_roundtrip_and_parity(pf, N, qs, force):
+    L = len(qs)
+    rng = np.random.default_rng(N + L + force)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs, force)
+    info = c.info()
+    assert info["psi"] == [o.psi(l) for l in range(L)]
+    expect_path = 1 if (force or any(q >= 1 << 45 for q in qs)) else 0
+    assert info["arith_path"] == [expect_path] * L
+    polys = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 2, 3, 4, 0, 0)])  # [7][L][N]
+    d = pf.to_device_u64(polys, _dev())
+    c.ntt_forward_(d)
+    ref = o.ntt_forward(polys)
+    assert (pf.to_host_u64(d) == ref).all()
+    c.ntt_inverse_(d)
+    assert (pf.to_host_u64(d) == polys).all()
+
+
+@pytest.mark.parametrize("N,qs,force", CONFIGS)
+def test_elementwise_parity(pf, N, qs, force):
+    L = len(qs)
+    rng = np.random.default_rng(N * 3 + L)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs, force)
+    a = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 2, 4, 0)])
+    b = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 1, 1, 3)])
+    da, db = pf.to_device_u64(a, _dev()), pf.to_device_u64(b, _dev())
+    assert (pf.to_host_u64(c.dyadic_mul(da, db)) == o.dyadic_mul(a, b)).all()
+    assert (pf.to_host_u64(c.add(da, db)) == o.addsub(a, b, o.ADD)).all()
+    assert (pf.to_host_u64(c.sub(da, db)) == o.addsub(a, b, o.SUB)).all()
+    assert (pf.to_host_u64(c.negate(da)) == o.addsub(a, None, o.NEG)).all()
+    # in place (out aliases a)
+    c.add(da, db, out=da)
+    assert (pf.to_host_u64(da) == o.addsub(a, b, o.ADD)).all()
+
+
+@pytest.mark.parametrize("N,qs,force", CONFIGS)
+def test_ct_pt_mul_all_flags(pf, N, qs, force):
+    L = len(qs)
+    B = 3
+    rng = np.random.default_rng(N * 5 + L + force)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs, force)
+
+    def rand(shape_prefix):
+        return np.stack([rng.integers(0, q, shape_prefix + (N,), dtype=np.uint64) for q in qs], axis=len(shape_prefix))
+
+    ct = rand((B, 2))                       # [B][2][L][N]
+    ct[0, 0] = np.stack([np.full(N, q - 1, dtype=np.uint64) for q in qs])
+    pt = o.ntt_forward(rand((B,)))          # [B][L][N] NTT form
+    pt[1] = np.stack([np.full(N, q - 1, dtype=np.uint64) for q in qs])
+    acc = rand((B, 2))
+    ct_ntt = o.ntt_forward(ct)
+    for flags in range(8):
+        src = ct_ntt if flags & pf.IN_NTT else ct
+        exp = o.ct_pt_mul(src, pt, flags, acc=acc)
+        d_out = pf.to_device_u64(acc, _dev())
+        got = c.ct_pt_mul(pf.to_device_u64(src, _dev()), pf.to_device_u64(pt, _dev()), out=d_out if flags & pf.ACCUMULATE else None, flags=flags)
+        assert (pf.to_host_u64(got) == exp).all(), flags
+    # broadcast plaintext, in-place output
+    d_ct = pf.to_device_u64(ct, _dev())
+    c.ct_pt_mul(d_ct, pf.to_device_u64(pt[:1], _dev()), out=d_ct)
+    assert (pf.to_host_u64(d_ct) == o.ct_pt_mul(ct, pt[:1])).all()
+
+
+def test_golden_vectors_on_gpu(pf, golden):
+    for ci in (4, 5):                                      # the N = 1024 fixtures (smaller N is below the kernel range)
+        g = lambda k: golden[f"c{ci}_{k}"]
+        q = int(g("q"))
+        for force in (False, True):
+            c = _ctx(pf, 1024, [q], force)
+            d = pf.to_device_u64(np.stack([g("a"), g("b")]), _dev())
+            c.ntt_forward_(d)
+            assert (pf.to_host_u64(d) == np.stack([g("ntt_a"), g("ntt_b")])).all()
+            ct = pf.to_device_u64(np.stack([g("a"), g("b")]).reshape(1, 2, 1, 1024), _dev())
+            out = pf.to_host_u64(c.ct_pt_mul(ct, pf.to_device_u64(g("ntt_b").reshape(1, 1, 1024), _dev()))).reshape(2, 1024)
+            assert (out[0] == g("a_times_b")).all()
+            da, db = pf.to_device_u64(g("a"), _dev()), pf.to_device_u64(g("b"), _dev())
+            assert (pf.to_host_u64(c.add(da, db)) == g("a_plus_b")).all()
+            assert (pf.to_host_u64(c.sub(da, db)) == g("a_minus_b")).all()
+            assert (pf.to_host_u64(c.negate(da)) == g("neg_a")).all()
+
+
+def test_config2_n4096_batch256(pf):
+    """BASELINE config 2: N=4096, 2 limbs, batch 256 ct x pt, whole batch against the oracle."""
+    N, qs, B = 4096, oracle.BFV_DEFAULT[4096][:2], 256
+    rng = np.random.default_rng(20250801 + 2)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs], axis=2)
+    pt = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs], axis=1)
+    got = pf.to_host_u64(c.ct_pt_mul(pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev())))
+    assert (got == o.ct_pt_mul(ct, pt)).all()
+
+
+def test_config3_full_size_properties(pf):
+    """BASELINE config 3 sizes (N=8192, 4 limbs, batch 1024): a 64-ciphertext slice against the oracle,
+    the whole batch through size-independent properties (round trip, linearity, fused == unfused)."""
+    N, qs, B = 8192, oracle.BFV_DEFAULT[8192][:4], 1024
+    L = len(qs)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    g = torch.Generator(device="cpu").manual_seed(20250801 + 3)
+    qt = torch.tensor(qs, dtype=torch.int64).view(1, 1, L, 1)
+    ct = (torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64) % qt).to(_dev())
+    pt = (torch.randint(0, 2**62, (B, L, N), generator=g, dtype=torch.int64) % qt[0]).to(_dev())
+    out = c.ct_pt_mul(ct, pt)
+    sl = slice(480, 544)
+    exp = o.ct_pt_mul(pf.to_host_u64(ct[sl]), pf.to_host_u64(pt[sl]))
+    assert (pf.to_host_u64(out[sl]) == exp).all()
+    # fused == unfused pipeline on the whole batch
+    tmp = ct.clone()
+    c.ntt_forward_(tmp)
+    tmp = c.dyadic_mul(tmp, pt.unsqueeze(1).expand(B, 2, L, N).contiguous())
+    c.ntt_inverse_(tmp)
+    assert torch.equal(tmp, out)
+    # round trip and linearity on the whole batch
+    rt = ct.clone()
+    c.ntt_forward_(rt)
+    f_ct = rt.clone()
+    c.ntt_inverse_(rt)
+    assert torch.equal(rt, ct)
+    other = torch.roll(ct, 1, 0).contiguous()
+    s = c.add(ct, other)
+    c.ntt_forward_(s)
+    f_other = other.clone()
+    c.ntt_forward_(f_other)
+    assert torch.equal(s, c.add(f_ct, f_other))
+    # accumulate: out + out == 2*out
+    acc = out.clone()
+    c.ct_pt_mul(ct, pt, out=acc, flags=pf.ACCUMULATE)
+    assert torch.equal(acc, c.add(out, out))
+
+
+def test_errors_are_statuses(pf):
+    c = _ctx(pf, 1024, oracle.BFV_DEFAULT[1024])
+    with pytest.raises(pf.PfError):
+        pf.RnsContext(1024, [0x7E00003], _dev())          # not prime / not 1 mod 2N
+    with pytest.raises(pf.PfError):
+        pf.RnsContext(32768, oracle.BFV_DEFAULT[32768][:1], _dev())   # degree not built yet
+    empty = torch.empty((0, 1024), dtype=torch.int64, device=_dev())
+    c.ntt_forward_(empty)                                  # empty batch is a no-op
+    with pytest.raises(ValueError):
+        c.ntt_forward_(torch.zeros(1000, dtype=torch.int64, device=_dev()))

@@ -1,0 +1,143 @@
+"""CPU tests of the oracle itself: Oracle A (C, SEAL-style lazy butterflies) against Oracle B (big-int
+mathematical definition), the committed golden vectors, the SURVEY prime/root table, and algebraic
+properties.  The reference ships no tests or fixtures for this path, so this is the
+pinning the oracle gets."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import bigint_ref as B
+from conftest import edge_poly
+
+
+def test_bfv_default_primes_and_minimal_roots():
+    for N, qs in oracle.BFV_DEFAULT.items():
+        for q in qs:
+            assert B.is_prime(q) and (q - 1) % (2 * N) == 0
+        o = oracle.Oracle(N, qs)
+        if N in oracle.MIN_PSI:
+            assert [o.psi(l) for l in range(len(qs))] == oracle.MIN_PSI[N]
+    bits = {N: sum(q.bit_length() for q in qs) for N, qs in oracle.BFV_DEFAULT.items()}
+    assert (bits[1024], bits[4096], bits[8192], bits[32768]) == (27, 109, 218, 881)   # SEAL BFVDefault totals
+
+
+def test_minimal_root_matches_bruteforce():
+    for N, q in [(8, 0x7E00001), (16, 0xFFFFEE001), (64, 0x7FFFFFD8001), (128, 0x7FFFFFFFE90001)]:
+        assert oracle.Oracle(N, [q]).psi(0) == B.min_psi(N, q)
+
+
+def test_golden_vectors(golden):
+    for ci in range(int(golden["n_cases"])):
+        g = lambda k: golden[f"c{ci}_{k}"]
+        N, q = int(g("N")), int(g("q"))
+        o = oracle.Oracle(N, [q])
+        assert o.psi(0) == int(g("psi"))
+        assert (o.ntt_forward(g("a")) == g("ntt_a")).all()
+        assert (o.ntt_forward(g("b")) == g("ntt_b")).all()
+        assert (o.ntt_inverse(g("ntt_a")) == g("a")).all()
+        assert (o.ntt_inverse(o.dyadic_mul(g("ntt_a"), g("ntt_b"))) == g("a_times_b")).all()
+        assert (o.addsub(g("a"), g("b"), o.ADD) == g("a_plus_b")).all()
+        assert (o.addsub(g("a"), g("b"), o.SUB) == g("a_minus_b")).all()
+        assert (o.addsub(g("a"), None, o.NEG) == g("neg_a")).all()
+        ct = np.stack([g("a"), g("b")]).reshape(1, 2, 1, N)
+        out = o.ct_pt_mul(ct, g("ntt_b").reshape(1, 1, N)).reshape(2, N)
+        assert (out[0] == g("a_times_b")).all()
+
+
+@pytest.mark.parametrize("N,q", [(256, 0x7E00001), (512, 0xFFFFEE001), (256, 0x7FFFFFD8001), (256, 0x7FFFFFFFE90001)])
+def test_ntt_against_direct_evaluation(N, q):
+    rng = np.random.default_rng(N + q % 1000)
+    o = oracle.Oracle(N, [q])
+    for kind in range(5):
+        a = edge_poly(rng, N, q, kind)
+        assert [int(x) for x in o.ntt_forward(a)] == B.ntt_direct([int(x) for x in a], q, o.psi(0))
+        assert (o.ntt_inverse(o.ntt_forward(a)) == a).all()
+
+
+def test_properties_full_size():
+    """N = 8192, 4 limbs: round trip, linearity, X-shift (multiplication by the monomial X)."""
+    N, qs = 8192, oracle.BFV_DEFAULT[8192][:4]
+    o = oracle.Oracle(N, qs)
+    rng = np.random.default_rng(3)
+    a = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs])
+    b = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs])
+    A, Bn = o.ntt_forward(a), o.ntt_forward(b)
+    assert (o.ntt_inverse(A) == a).all()
+    assert (o.ntt_forward(o.addsub(a, b, o.ADD)) == o.addsub(A, Bn, o.ADD)).all()
+    x = np.zeros_like(a)
+    x[:, 1] = 1                                            # the monomial X
+    shifted = o.ntt_inverse(o.dyadic_mul(A, o.ntt_forward(x)))
+    expect = np.roll(a, 1, axis=1)
+    for l, q in enumerate(qs):
+        expect[l, 0] = (q - int(a[l, -1])) % q             # X^N = -1
+    assert (shifted == expect).all()
+
+
+def test_multi_limb_ct_pt_against_crt():
+    """Two-limb product checked through CRT reconstruction against a big-int negacyclic product."""
+    N, qs = 64, [0x7FFFFFD8001, 0xFFFFFFFC001]
+    assert all((q - 1) % (2 * N) == 0 for q in qs)
+    o = oracle.Oracle(N, qs)
+    rng = np.random.default_rng(11)
+    M = qs[0] * qs[1]
+    big_a = [int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**20)) % M for _ in range(N)]
+    big_b = [int(rng.integers(0, 2**62)) % M for _ in range(N)]
+    a = np.array([[x % q for x in big_a] for q in qs], dtype=np.uint64)
+    b = np.array([[x % q for x in big_b] for q in qs], dtype=np.uint64)
+    ct = np.stack([a, a]).reshape(1, 2, 2, N)
+    out = o.ct_pt_mul(ct, o.ntt_forward(b).reshape(1, 2, N)).reshape(2, 2, N)
+    ref = B.negacyclic_mul(big_a, big_b, M)
+    for j in range(N):
+        x, _ = B.crt([int(out[0, 0, j]), int(out[0, 1, j])], qs)
+        assert x == ref[j]
+
+
+def test_ct_pt_flags():
+    N, qs = 1024, [0x7E00001]
+    o = oracle.Oracle(N, qs)
+    rng = np.random.default_rng(5)
+    ct = rng.integers(0, qs[0], (3, 2, 1, N), dtype=np.uint64)
+    pt = o.ntt_forward(rng.integers(0, qs[0], (3, 1, N), dtype=np.uint64))
+    acc = rng.integers(0, qs[0], (3, 2, 1, N), dtype=np.uint64)
+    plain = o.ct_pt_mul(ct, pt)
+    assert (o.ct_pt_mul(o.ntt_forward(ct), pt, o.IN_NTT) == plain).all()
+    assert (o.ntt_inverse(o.ct_pt_mul(ct, pt, o.OUT_NTT)) == plain).all()
+    assert (o.ct_pt_mul(ct, pt, o.ACCUMULATE, acc=acc) == o.addsub(acc, plain, o.ADD)).all()
+    assert (o.ct_pt_mul(ct, pt[:1]) [0] == plain[0]).all()     # broadcast plaintext
+
+
+def test_precise_search_matches_reference_semantics():
+    """server_lib.cpp:151-162: float accumulator, pow() through double; exact on SIFT-like integer data."""
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, (500, 128)).astype(np.float32)
+    xq = rng.integers(0, 256, (5, 128)).astype(np.float32)
+    ids = rng.integers(0, 500, (5, 200)).astype(np.int64)
+    got = oracle.precise_search(base, xq, ids)
+    exact = ((base[ids].astype(np.float64) - xq[:, None, :].astype(np.float64)) ** 2).sum(-1)
+    assert (got.astype(np.float64) == exact).all()
+    # literal python restatement of the loop on gaussian data
+    gb, gq = rng.standard_normal((50, 16)).astype(np.float32), rng.standard_normal((2, 16)).astype(np.float32)
+    gi = rng.integers(0, 50, (2, 7)).astype(np.int64)
+    got = oracle.precise_search(gb, gq, gi)
+    for i in range(2):
+        for j in range(7):
+            dist = np.float32(0.0)
+            for k in range(16):
+                diff = np.float32(gb[gi[i, j], k] - gq[i, k])
+                dist = np.float32(np.float64(dist) + np.float64(diff) ** 2)
+            assert got[i, j] == dist
+
+
+def test_flat_l2_search_oracle():
+    rng = np.random.default_rng(2)
+    xb = rng.integers(0, 256, (3000, 128)).astype(np.float32)
+    xq = rng.integers(0, 256, (7, 128)).astype(np.float32)
+    D, I = oracle.flat_l2_search(xb, xq, 20)
+    d = ((xb[None].astype(np.float64) - xq[:, None].astype(np.float64)) ** 2).sum(-1)
+    for i in range(7):
+        order = np.lexsort((np.arange(3000), d[i]))[:20]
+        assert (I[i] == order).all() and (D[i].astype(np.float64) == d[i][order]).all()
+    D2, I2 = oracle.flat_l2_search(xb, xq, 20, mode=1)      # literal client_lib.cpp:55-67 accumulation
+    assert (I2 == I).all() and (D2 == D).all()
+    D3, I3 = oracle.flat_l2_search(xb[:5], xq, 8)           # k > nb: (+inf, -1) padding
+    assert (I3[:, 5:] == -1).all() and np.isinf(D3[:, 5:]).all()

@@ -1,0 +1,95 @@
+"""CPU tests: (1) the device NTT core executed on the host lane simulator against the oracle, bit-exact;
+(2) host-side table construction; (3) the C-ABI library loads and exports every symbol the header declares
+(no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, edge_poly
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+SIM_CASES = [  # (logn, q, arithmetic) 0 = exact-FP64, 1 = u64 Shoup
+    (10, 0x7E00001, 0), (10, 0x7E00001, 1),
+    (12, 0xFFFFEE001, 0), (12, 0x1FFFFE0001, 1),
+    (13, 0x7FFFFFD8001, 0), (13, 0xFFFFFEBC001, 0), (13, 0xFFFFFFFC001, 1),
+    (11, 0x3FFFFFFF000001, 1), (13, 0x7FFFFFFFE90001, 1), (14, 0x7FFFFFFFE90001, 1),
+]
+
+
+@pytest.mark.parametrize("logn,q,arith", SIM_CASES)
+def test_device_core_on_host_simulator(sim_lib, logn, q, arith):
+    N = 1 << logn
+    assert (q - 1) % (2 * N) == 0
+    o = oracle.Oracle(N, [q])
+    assert sim_lib.pf_sim_psi(logn, q) == o.psi(0)
+    rng = np.random.default_rng(logn * 7 + arith)
+    kinds = (0, 1) if logn >= 13 else (0, 1, 2, 3, 4)
+    for kind in kinds:
+        a = edge_poly(rng, N, q, kind)
+        b = edge_poly(rng, N, q, 1 - kind if kind < 2 else 0)
+        dst = np.empty(N, dtype=np.uint64)
+        assert sim_lib.pf_sim_run(logn, q, arith, 0, 0, _p(a), _p(a), _p(dst)) == 0
+        A = o.ntt_forward(a)
+        assert (dst == A).all()
+        assert sim_lib.pf_sim_run(logn, q, arith, 1, 0, _p(A), _p(A), _p(dst)) == 0
+        assert (dst == a).all()
+        bn = o.ntt_forward(b)
+        for flags in range(8):
+            src = A if flags & 2 else a
+            acc0 = edge_poly(rng, N, q, 0)
+            dst = acc0.copy()
+            exp = o.ct_pt_mul(np.stack([src, src]).reshape(1, 2, 1, N), bn.reshape(1, 1, N), flags,
+                              acc=np.stack([acc0, acc0]).reshape(1, 2, 1, N)).reshape(2, N)[0]
+            assert sim_lib.pf_sim_run(logn, q, arith, 2, flags, _p(src), _p(bn), _p(dst)) == 0
+            assert (dst == exp).all(), (flags, kind)
+
+
+def test_simulator_golden_n1024(sim_lib, golden):
+    for ci in (4, 5):
+        g = lambda k: golden[f"c{ci}_{k}"]
+        q = int(g("q"))
+        dst = np.empty(1024, dtype=np.uint64)
+        for arith in (0, 1):
+            a = np.ascontiguousarray(g("a"))
+            assert sim_lib.pf_sim_run(10, q, arith, 0, 0, _p(a), _p(a), _p(dst)) == 0
+            assert (dst == g("ntt_a")).all()
+            nb = np.ascontiguousarray(g("ntt_b"))
+            assert sim_lib.pf_sim_run(10, q, arith, 2, 0, _p(a), _p(nb), _p(dst)) == 0
+            assert (dst == g("a_times_b")).all()
+
+
+def test_fp64_path_rejected_for_wide_primes(sim_lib):
+    a = np.zeros(8192, dtype=np.uint64)
+    assert sim_lib.pf_sim_run(13, 0x7FFFFFFFE90001, 0, 0, 0, _p(a), _p(a), _p(a)) == -3
+
+
+def test_library_loads_and_exports_header_symbols():
+    import prefhetch_amd as pf
+    header = open(os.path.join(ROOT, "include", "prefhetch_hip.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pf.SYMBOLS), declared ^ set(pf.SYMBOLS)
+    for name in declared:
+        assert hasattr(pf.lib, name)
+    assert pf.lib.pf_status_str(0) == b"ok"
+    # error path without a device: status code, message, no exception, no abort
+    n = C.c_int(-1)
+    st = pf.lib.pf_device_count(C.byref(n))
+    assert st in (0, -4)
+    h = C.c_void_p()
+    st = pf.lib.pf_ctx_create(C.byref(h), 0, 1000, 1, (C.c_uint64 * 1)(0x7E00001))
+    assert st == -2 and b"power of two" in pf.lib.pf_last_error()
+
+
+def test_python_api_refuses_cpu_tensors():
+    import torch
+    import prefhetch_amd as pf
+    with pytest.raises(ValueError):
+        pf.RnsContext(1024, [0x7E00001], device="cpu")
