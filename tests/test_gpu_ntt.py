@@ -39,7 +39,8 @@ CONFIGS = [  # (N, moduli, force_u64)
     (8192, oracle.BFV_DEFAULT[8192][:4], False),
     (8192, oracle.BFV_DEFAULT[8192], True),
     (8192, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001], False),   # 55-bit primes at N=8192 -> u64 path
-    (16384, [0x7FFFFFFFE90001, 0xFFFFFEBC001], False),
+    (16384, [0x7FFFFFFFE90001, 0x7FFFFFD8001], False),  # mixed widths -> u64 path
+    (16384, [0x7FFFFFD8001, 0x7FFFFFC8001], False),      # exact-FP64 path at N=16384
 ]
 
 
