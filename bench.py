@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE config 3 (per GPU): one STEP = one pass of the
+server-side encrypted-query hot path over a batch of 1024 queries:
+
+    stage A  IndexFlatL2 pre-filter: 1024 fp32 queries x 1,000,000 x 128 base -> top-200 (D, I)
+    stage B  homomorphic distance:   1024 ciphertexts [2][4][8192] (coefficient form) x 1024 NTT-form
+             plaintexts -> 1024 ciphertexts (coefficient form), ONE fused launch
+             (= 8 forward limb-NTTs + 8 dyadic products + 8 inverse limb-NTTs per encrypted query)
+    stage C  (N > 1 only) ONE RCCL all-gather of the packed per-rank top-k block [1024][200]{i64,f32}
+
+value = encrypted queries/s over the whole step, all ranks (weak scaling: 1024 queries per GPU, the
+base matrix and tables replicated).  Inputs are resident in HBM before the timed region.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak = fp32 vector peak
+
+N_RING, LIMBS = 8192, 4
+MODULI = [0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001]   # SEAL BFVDefault(8192) data primes
+NB, DIM, TOPK = 1_000_000, 128, 200
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="encrypted queries per GPU per step")
+    ap.add_argument("--nb", type=int, default=NB)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default min(16, cores))")
+    return ap.parse_args()
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU restatement of the SEAL/faiss algorithms; the reference itself cannot be built here)
+    timed on the host cores on a bounded sample of the same workload: kind = "port"."""
+    import oracle
+    rng = np.random.default_rng(20250801 + 3)
+    o = oracle.Oracle(N_RING, MODULI)
+    n_ct, n_q = 1024, 64
+    ct = np.stack([rng.integers(0, q, (n_ct, 2, N_RING), dtype=np.uint64) for q in MODULI], axis=2)
+    pt = np.stack([rng.integers(0, q, (n_ct, N_RING), dtype=np.uint64) for q in MODULI], axis=1)
+    o.ct_pt_mul(ct[:32], pt[:32], threads=threads)                      # warm-up
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o.ct_pt_mul(ct, pt, threads=threads)
+        reps.append(time.perf_counter() - t0)
+    t_ct = sorted(reps)[1] / n_ct
+    xb = rng.integers(0, 256, (NB, DIM), dtype=np.uint8).astype(np.float32)
+    xq = rng.integers(0, 256, (n_q, DIM), dtype=np.uint8).astype(np.float32)
+    oracle.flat_l2_search(xb[:10000], xq, TOPK, threads=threads, f32=True)
+    t0 = time.perf_counter()
+    oracle.flat_l2_search(xb, xq, TOPK, threads=threads, f32=True)
+    t_q = (time.perf_counter() - t0) / n_q
+    return {
+        "value": 1.0 / (t_ct + t_q), "unit": "encrypted queries/s", "cores": threads, "kind": "port",
+        "sample": f"{n_ct} ct x pt (N=8192, 4 limbs, median of 3) + {n_q} flat-L2 queries vs 1M x 128 (k=200), "
+                  f"OpenMP {threads} threads; restated CPU baseline (SEAL/faiss sources unavailable offline)",
+        "ctpt_only_qps": 1.0 / t_ct, "prefilter_only_qps": 1.0 / t_q,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+
+    import prefhetch_amd as pf
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(20250801 + 3 + 1000 * rank)
+    ct = torch.stack([torch.randint(0, q, (B, 2, N_RING), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=2).contiguous()
+    pt = torch.stack([torch.randint(0, q, (B, N_RING), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=1).contiguous()
+    out = torch.empty_like(ct)
+    gb = torch.Generator(device=dev).manual_seed(20250801 + 3)      # base matrix replicated: same seed on every rank
+    xb = torch.randint(0, 256, (args.nb, DIM), generator=gb, device=dev, dtype=torch.int32).to(torch.float32)
+    xq = torch.randint(0, 256, (B, DIM), generator=g, device=dev, dtype=torch.int32).to(torch.float32)
+    ctx = pf.RnsContext(N_RING, MODULI, dev)
+    flat = pf.FlatL2(xb, dev)
+    flat.reserve(B, TOPK)
+    del xb
+    gathered = torch.empty((world, B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def step(i=None):
+        e = ev[i] if i is not None else None
+        if e: e[0].record()
+        D, I = flat.search(xq, TOPK)                               # stage A
+        if e: e[1].record()
+        ctx.ct_pt_mul(ct, pt, out=out)                             # stage B (one launch)
+        if e: e[2].record()
+        if world > 1:                                              # stage C: one collective, packed (I, D)
+            packed = torch.cat([I.view(torch.int32).view(B, TOPK, 2), D.view(torch.int32).unsqueeze(-1)], dim=-1).contiguous()
+            dist.all_gather_into_tensor(gathered, packed)
+        if e: e[3].record()
+        return D, I
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_a = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_b = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_c = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_q = B * world
+        # fused ct x pt kernel: read ct 2LN*8 + read pt LN*8 + write 2LN*8 = 40*L*N bytes per encrypted query
+        alg_bytes = 40 * LIMBS * N_RING * B
+        ach = alg_bytes / (ms_b * 1e-3) / 1e9
+        flops = 2.0 * B * args.nb * DIM
+        tf = flops / (ms_a * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_ctpt_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "encrypted queries/sec at N=8192, 4 RNS limbs; NTT HBM GB/s vs roofline",
+            "value": total_q / (elapsed / args.steps), "unit": "encrypted queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (exact-FP64 butterflies) + f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3 per GPU: flat-L2 top-200 pre-filter of 1024 queries over 1M x 128 fp32 "
+                                   "+ fused ct x pt (N=8192, 4 limbs, batch 1024, coefficient form in and out)"
+                                   + (" + one RCCL all-gather of packed top-k" if world > 1 else ""),
+                       "ring_dim": N_RING, "limbs": LIMBS, "batch_per_gpu": B, "nb": args.nb, "dim": DIM, "k": TOPK,
+                       "parallelism": f"query-sharded x{world}, base matrix replicated"},
+            "stages_ms": {"prefilter": ms_a, "ct_x_pt": ms_b, "gather": ms_c},
+            "ct_x_pt_only_qps_per_gpu": B / (ms_b * 1e-3),
+            "roofline": {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_b},
+            "roofline_prefilter": {"kernel": "k_l2_tile (+ k_select_chunk), whole stage", "bound": "mfma", "achieved": tf,
+                                   "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TF,
+                                   "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(threads)
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
