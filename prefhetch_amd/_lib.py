@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprefhetch_hip.so")
+# PREFHETCH_HIP_LIB overrides the library path (kernel experiments); it must still be a HIP build of the C ABI
+LIB_PATH = os.environ.get("PREFHETCH_HIP_LIB") or os.path.join(_HERE, "lib", "libprefhetch_hip.so")
 
 # every symbol include/prefhetch_hip.h declares
 SYMBOLS = [

@@ -1,10 +1,17 @@
 // ntt_core.hpp -- register-resident negacyclic NTT / ct x pt core for gfx950 (MI355X).
 //
 // One workgroup transforms one limb-polynomial of N = 2^LOGN coefficients.  Every thread keeps
-// R = 2^LOGR coefficients in VGPRs and runs LOGR radix-2 stages on them without touching memory
-// ("pass"); between passes the workgroup re-distributes coefficients through LDS so the next
-// LOGR index bits become thread-local ("exchange").  N = 8192: 256 threads x 32 coefficients,
-// passes over index bits 12..8 | 7..3 | 2..0, two exchanges per transform, 64 KiB of LDS.
+// R = 2^LOGR coefficients in VGPRs and runs radix-2 stages on them without touching memory ("pass");
+// between passes the workgroup re-distributes coefficients through LDS so the next index bits become
+// thread-local ("exchange").  N = 8192: 256 threads x 32 coefficients, passes over index bits
+// 12..8 | 7..3 | 2..0, two exchanges per transform, 64 KiB of LDS.
+//
+// Layouts.  Pass p < P-1 owns the contiguous index bits [a, a+LOGR); the thread id fills the rest.
+// The LAST pass owns the low `nl` bits it still has to transform plus the TOP LOGR-nl bits (carried):
+// a lane then holds runs of 2^nl consecutive coefficients and consecutive lanes hold consecutive
+// runs, so (1) its twiddles, (2) the NTT-form plaintext of the fused kernel and (3) NTT-form input /
+// output of the stand-alone transforms are all read and written lane-contiguously from HBM, with no
+// extra pass through LDS.  Coefficient-form data is read/written in layout 0 (lane-contiguous too).
 //
 // Replaces (behaviour, not code): SEAL util::ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey /
 // dyadic_product_coeffmod and Evaluator::multiply_plain, which the reference links
@@ -23,10 +30,11 @@
 // index maps and the floating-point error analysis bit-for-bit on a machine without a GPU.
 #pragma once
 #include <stdint.h>
+#include "lds_swizzle_tab.hpp"
 
 #if defined(__HIPCC__)
 #define PF_HD __device__ __forceinline__
-// keeps hipcc's scheduler from hoisting the next phase's loads into this one (register budget)
+// keeps hipcc's scheduler from re-serialising the batched arithmetic below
 #define PF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define PF_HD inline
@@ -35,8 +43,10 @@
 
 namespace pf {
 
-struct TwF64 { double w, wq; };        // twiddle and fl(w/q)
 struct TwU64 { uint64_t w, wq; };      // twiddle and floor(w*2^64/q)  (SEAL MultiplyUIntModOperand)
+struct TwF64 { double w; };            // table entry of the FP64 back-end: the twiddle as a double
+struct TwF64R { double w, wq; };       // ... resolved on load: wq = fl(w * fl(1/q))
+struct alignas(16) U64x2 { uint64_t x, y; };
 
 PF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 PF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
@@ -52,32 +62,40 @@ PF_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 // ------------------------------------------------------------------------------------------------
 // Geometry
 // ------------------------------------------------------------------------------------------------
+#ifndef PF_LOGR_LARGE
+#define PF_LOGR_LARGE 5        // log2(coefficients per thread) for N >= 4096
+#endif
 template <int LOGN_>
 struct Geo {
     static constexpr int LOGN = LOGN_;
     static constexpr int N = 1 << LOGN;
-    static constexpr int LOGR = LOGN >= 12 ? 5 : 4;
+    static constexpr int LOGR = LOGN >= 12 ? PF_LOGR_LARGE : 4;
     static constexpr int R = 1 << LOGR;
     static constexpr int T = N / R;                               // threads per workgroup
     static constexpr int P = (LOGN + LOGR - 1) / LOGR;            // passes per transform
-    // lowest thread-local index bit of pass p
+    static constexpr int LAST = P - 1;
+    // pass p transforms the nl(p) index bits [a(p), a(p)+nl(p)); the last pass also carries the top nh bits
+    static constexpr int nl(int p) { return p == P - 1 ? LOGN - (P - 1) * LOGR : LOGR; }
+    static constexpr int nh(int p) { return LOGR - nl(p); }
     static constexpr int a(int p) { return p == P - 1 ? 0 : LOGN - (p + 1) * LOGR; }
-    static constexpr int bhi(int p) { return LOGN - 1 - p * LOGR; }   // highest bit transformed by pass p
-    static constexpr int blo(int p) { return a(p); }                   // lowest bit transformed by pass p
-    // coefficient index of register k of thread tid in the layout of pass p
+    // coefficient index = base(p, tid) | koff(p, k)
+    static constexpr int koff(int p, int k) {
+        return ((k >> nl(p)) << (LOGN - nh(p))) | ((k & ((1 << nl(p)) - 1)) << a(p));
+    }
     static PF_HD int base(int p, int tid) {
         const int aa = a(p);
         const int low = tid & ((1 << aa) - 1), high = tid >> aa;
-        return (high << (aa + LOGR)) | low;
+        return (high << (aa + nl(p))) | low;
     }
-    // LDS slot of coefficient i for an exchange between two layouts, p being the one with the lower
-    // thread-local field: XOR the index bits above that field into the bank-selecting low bits so
-    // that the 32 lanes of a ds_read_b64 group (and the 16 of a ds_write_b64 group) hit different
-    // 8-byte slots from either layout (MI355X_MICROARCH.md, LDS table).
-    static PF_HD int slot(int p, int i) {
-        const int aa = a(p);   // callers pass the later (finer) of the two layouts an exchange joins
-        if (aa >= 5) return i;
-        return i ^ (((i >> (aa + LOGR)) & ((1 << (5 - aa)) - 1)) << aa);
+    // LDS slot of coefficient i in the exchange between passes `pair` and `pair`+1 (GF(2)-linear, see table)
+    template <int PAIR>
+    static PF_HD int slot(int i) {
+        constexpr SwzEntry e = swz_lookup(LOGN, LOGR, PAIR);
+        int s = i;
+        if constexpr (e.t[0].w != 0) s ^= ((i >> e.t[0].s) & ((1 << e.t[0].w) - 1)) << e.t[0].d;
+        if constexpr (e.t[1].w != 0) s ^= ((i >> e.t[1].s) & ((1 << e.t[1].w) - 1)) << e.t[1].d;
+        if constexpr (e.t[2].w != 0) s ^= ((i >> e.t[2].s) & ((1 << e.t[2].w) - 1)) << e.t[2].d;
+        return s;
     }
 };
 
@@ -85,17 +103,22 @@ struct Geo {
 // Arithmetic back-ends
 // ------------------------------------------------------------------------------------------------
 // ArithF64.  Invariants (q < 2^45, LOGN <= 15):
-//   * every value is an integer-valued double with |v| <= 2^50 at any modular product input, so
-//     c = rint(fl(v*wq)) is within 1 of v*w/q and r = v*w - c*q is computed EXACTLY:
-//     h = fl(v*w), l = v*w - h (exact, FMA), d = fl(h - c*q) is exact because h - c*q = r - l is an
-//     integer below 2^47, r = d + l.  |r| < q (0.75 q at the bounds above).
+//   * every value is an integer-valued double with |v| <= 2^50 at any modular product input.  With
+//     wq = fl(w*fl(1/q)) the estimate fl(v*wq) is within 3*2^-53*|v*w/q| <= 3/8 of v*w/q, so
+//     c = rint(.) is within 1 of it and r = v*w - c*q is computed EXACTLY: h = fl(v*w),
+//     l = v*w - h (exact, FMA), d = fl(h - c*q) is exact because h - c*q = r - l is an integer below
+//     2^47, r = d + l.  |r| < 0.875 q.
 //   * forward: X' = X + T, Y' = X - T with |T| < q, so |X| <= q*(1 + LOGN) after the last stage;
 //     (1+15)*2^45 = 2^49: no intermediate correction is ever needed.
 //   * inverse: X' = X + Y doubles per stage; values are re-centred (|v| <= q/2) once per pass, so a
 //     5-stage pass peaks at 32 q <= 2^50.
+// The batched members work phase by phase over NB independent operands with scheduling fences in
+// between: hipcc otherwise emits each product as one serial dependent chain.
 struct ArithF64 {
     using V = double;
     using Tw = TwF64;
+    using TwR = TwF64R;
+    static constexpr bool PREFETCH_TW = true;      // 8-byte twiddles: a whole pass's worth fits in registers across an exchange
     double q, qinv;
 
     static PF_HD V from_u64(uint64_t x) {            // x < 2^52 : set exponent of 2^52, subtract
@@ -104,59 +127,96 @@ struct ArithF64 {
     static PF_HD uint64_t to_u64(V v) {              // 0 <= v < 2^51, integer valued
         return d2u(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
     }
-    PF_HD V mulmod(V y, Tw t) const {
-        const double h = y * t.w;
-        const double l = __builtin_fma(y, t.w, -h);
-        const double c = __builtin_rint(y * t.wq);
-        const double d = __builtin_fma(-c, q, h);
-        return d + l;
+    PF_HD TwR resolve(Tw t) const { return TwR{t.w, t.w * qinv}; }
+    template <int NB>
+    PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {     // y[i] <- y[i]*t[i] (mod q), |.| < q
+        double h[NB], l[NB], c[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) h[i] = y[i] * t[i].w;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = y[i] * t[i].wq;
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) l[i] = __builtin_fma(y[i], t[i].w, -h[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = __builtin_rint(c[i]);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) h[i] = __builtin_fma(-c[i], q, h[i]);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y[i] = h[i] + l[i];
     }
-    PF_HD V mulmod2(V a, V b) const {                // both operands variable (dyadic product)
-        const double h = a * b;
-        const double l = __builtin_fma(a, b, -h);
-        const double c = __builtin_rint(h * qinv);
-        const double d = __builtin_fma(-c, q, h);
-        return d + l;
+    template <int NB>
+    PF_HD void dyadic_n(V (&a)[NB], const V (&b)[NB]) const {       // a[i] <- a[i]*b[i] (mod q), both variable
+        double h[NB], l[NB], c[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) h[i] = a[i] * b[i];
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) l[i] = __builtin_fma(a[i], b[i], -h[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = h[i] * qinv;
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = __builtin_rint(c[i]);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) h[i] = __builtin_fma(-c[i], q, h[i]);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a[i] = h[i] + l[i];
     }
-    PF_HD V recentre(V v) const { return __builtin_fma(-__builtin_rint(v * qinv), q, v); }
-    PF_HD void fwd_bfly(V &x, V &y, Tw t) const { const V m = mulmod(y, t); y = x - m; x = x + m; }
-    PF_HD void inv_bfly(V &x, V &y, Tw t) const { const V s = x + y, d = x - y; x = s; y = mulmod(d, t); }
-    PF_HD void inv_last(V &x, V &y, Tw tn, Tw t) const { const V s = x + y, d = x - y; x = mulmod(s, tn); y = mulmod(d, t); }
-    PF_HD void pass_reduce(V &v) const { v = recentre(v); }
-    PF_HD V dyadic(V a, V b) const { return mulmod2(a, b); }
+    template <int NB>
+    PF_HD void recentre_n(V (&v)[NB]) const {                       // v <- v - q*rint(v/q)
+        double c[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = v[i] * qinv;
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c[i] = __builtin_rint(c[i]);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = __builtin_fma(-c[i], q, v[i]);
+    }
+    PF_HD void fwd_combine(V &x, V &y, V m) const { y = x - m; x = x + m; }
+    PF_HD void inv_split(V &x, V y, V &d) const { d = x - y; x = x + y; }
+    template <int NB> PF_HD void pass_reduce_n(V (&v)[NB]) const { recentre_n<NB>(v); }
+    template <int NB> PF_HD void for_dyadic_n(V (&)[NB]) const {}
     PF_HD V add(V a, V b) const { return a + b; }
-    // canonical residue in [0,q) from any in-range lazy value
-    PF_HD V canon(V v) const { V r = recentre(v); return r < 0.0 ? r + q : r; }
-    // canonical residue from |v| < q
-    PF_HD V canon_small(V v) const { return v < 0.0 ? v + q : v; }
-    // canonical residue from -q < v < 2q
-    PF_HD V canon_sum(V v) const { V r = v < 0.0 ? v + q : v; return r >= q ? r - q : r; }
-    static PF_HD V for_dyadic(V v) { return v; }
+    template <int NB> PF_HD void canon_n(V (&v)[NB]) const {        // [0,q) from any in-range lazy value
+        recentre_n<NB>(v);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = v[i] < 0.0 ? v[i] + q : v[i];
+    }
+    PF_HD V canon_small(V v) const { return v < 0.0 ? v + q : v; }                       // from |v| < q
+    PF_HD V canon_sum(V v) const { V r = v < 0.0 ? v + q : v; return r >= q ? r - q : r; }   // from -q < v < 2q
 };
 
 // ArithU64: SEAL's lazy Harvey butterflies.  forward values live in [0,4q), inverse values in [0,2q).
 struct ArithU64 {
     using V = uint64_t;
     using Tw = TwU64;
+    using TwR = TwU64;
+    static constexpr bool PREFETCH_TW = false;     // 16-byte twiddles: fetched after the exchange (register budget)
     uint64_t q, two_q, ratio0, ratio1;               // ratio = floor(2^128/q)
 
     static PF_HD V from_u64(uint64_t x) { return x; }
     static PF_HD uint64_t to_u64(V v) { return v; }
-    PF_HD V mul_lazy(V y, Tw t) const { return y * t.w - mulhi64(y, t.wq) * q; }     // [0,2q)
+    PF_HD TwR resolve(Tw t) const { return t; }
     PF_HD V guard(V v) const { return v >= two_q ? v - two_q : v; }
-    PF_HD void fwd_bfly(V &x, V &y, Tw t) const {
-        const V u = guard(x), m = mul_lazy(y, t);
-        x = u + m; y = u + two_q - m;
+    template <int NB>
+    PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {
+        uint64_t hi[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) hi[i] = mulhi64(y[i], t[i].wq);
+        PF_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y[i] = y[i] * t[i].w - hi[i] * q;                 // [0,2q)
     }
-    PF_HD void inv_bfly(V &x, V &y, Tw t) const {
-        const V s = guard(x + y), d = x + two_q - y;
-        x = s; y = mul_lazy(d, t);
-    }
-    PF_HD void inv_last(V &x, V &y, Tw tn, Tw t) const {
-        const V s = guard(x + y), d = x + two_q - y;
-        x = mul_lazy(s, tn); y = mul_lazy(d, t);
-    }
-    PF_HD void pass_reduce(V &) const {}
+    PF_HD void fwd_combine(V &x, V &y, V m) const { const V u = guard(x); x = u + m; y = u + two_q - m; }
+    PF_HD void inv_split(V &x, V y, V &d) const { d = x + two_q - y; x = guard(x + y); }
+    template <int NB> PF_HD void pass_reduce_n(V (&)[NB]) const {}
     // Barrett 128->64 (SEAL dyadic_product_coeffmod); operands must be canonical
     PF_HD V dyadic(V a, V b) const {
         const uint64_t z0 = a * b, z1 = mulhi64(a, b);
@@ -171,11 +231,19 @@ struct ArithU64 {
         const uint64_t r = z0 - qhat * q;
         return r >= q ? r - q : r;
     }
+    template <int NB>
+    PF_HD void dyadic_n(V (&a)[NB], const V (&b)[NB]) const {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a[i] = dyadic(a[i], b[i]);
+    }
     PF_HD V add(V a, V b) const { return a + b; }
-    PF_HD V canon(V v) const { V r = guard(v); return r >= q ? r - q : r; }          // from [0,4q)
+    template <int NB> PF_HD void canon_n(V (&v)[NB]) const {                          // from [0,4q)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { V r = guard(v[i]); v[i] = r >= q ? r - q : r; }
+    }
+    template <int NB> PF_HD void for_dyadic_n(V (&v)[NB]) const { canon_n<NB>(v); }
     PF_HD V canon_small(V v) const { return v >= q ? v - q : v; }                    // from [0,2q)
     PF_HD V canon_sum(V v) const { V r = v >= two_q ? v - two_q : v; return r >= q ? r - q : r; }   // from [0,3q)
-    PF_HD V for_dyadic(V v) const { return canon(v); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -184,147 +252,279 @@ struct ArithU64 {
 // Twiddle tables are indexed like SEAL's root_powers: entry m+i (m = 2^s groups, group i) holds
 // psi^bitrev(m+i); the inverse table holds the modular inverse of the same entry, except
 // inv[1] = psi^-bitrev(1) * N^-1 and inv[0] = N^-1 (both only used by the last inverse layer).
+// The butterfly of local bit kb pairs registers k0 (bit kb clear) and k0 | 2^kb; its twiddle is entry
+// m + (i >> (b+1)) for the global bit b = a + kb and i the coefficient index of register k0.
+
+constexpr int NBATCH = 4;     // independent butterflies issued together (covers the FP64 dependent-issue latency)
+
+// The twiddles of one pass, fetched up front so the caller can issue them BEFORE the exchange that precedes
+// the pass (plain loads stay in flight across s_barrier): entry off(kb) + g is the twiddle of stage kb,
+// register group g = k0 >> (kb+1).
+template <class G, class A, int PASS>
+struct PassTw {
+    static constexpr int NL = G::nl(PASS);
+    static constexpr int off(int kb) { int o = 0; for (int j = 0; j < kb; ++j) o += G::R >> (j + 1); return o; }
+    static constexpr int COUNT = off(NL);
+    typename A::Tw t[COUNT];
+
+    PF_HD void load(const typename A::Tw *__restrict__ tw, int tid) {
+        constexpr int aa = G::a(PASS);
+        const int tb = PASS == 0 ? 0 : G::base(PASS, tid);      // pass 0: every twiddle is workgroup-uniform
+#pragma unroll
+        for (int kb = 0; kb < NL; ++kb) {
+            const int sh = aa + kb + 1;
+            const typename A::Tw *__restrict__ tp = tw + (1 << (G::LOGN - sh)) + (tb >> sh);
+#pragma unroll
+            for (int g = 0; g < (G::R >> (kb + 1)); ++g) t[off(kb) + g] = tp[G::koff(PASS, g << (kb + 1)) >> sh];
+        }
+    }
+};
 
 template <class G, class A, int PASS>
-PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw, int tid) {
-    constexpr int aa = G::a(PASS);
-    constexpr int kb_hi = G::bhi(PASS) - aa, kb_lo = G::blo(PASS) - aa;
-    const int high = PASS == 0 ? 0 : (tid >> aa);
+PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
+    using V = typename A::V;
+    using TwR = typename A::TwR;
 #pragma unroll
-    for (int kb = kb_hi; kb >= kb_lo; --kb) {
-        const int m = 1 << (G::LOGN - 1 - (kb + aa));
-        const typename A::Tw *__restrict__ tp = tw + m + (high << (G::LOGR - 1 - kb));
+    for (int kb = G::nl(PASS) - 1; kb >= 0; --kb) {
 #pragma unroll
-        for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
-            const typename A::Tw t = tp[g];
+        for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
+            V ys[NBATCH];
+            TwR ts[NBATCH];
 #pragma unroll
-            for (int j = 0; j < (1 << kb); ++j) {
-                const int k0 = (g << (kb + 1)) | j, k1 = k0 | (1 << kb);
-                ar.fwd_bfly(r[k0], r[k1], t);
+            for (int i = 0; i < NBATCH; ++i) {
+                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
+                ys[i] = r[k0 | (1 << kb)];
+                ts[i] = ar.resolve(T.t[PassTw<G, A, PASS>::off(kb) + (b >> kb)]);
+            }
+            ar.template mul_tw_n<NBATCH>(ys, ts);
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) {
+                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
+                ar.fwd_combine(r[k0], r[k0 | (1 << kb)], ys[i]);
             }
         }
     }
 }
 
 template <class G, class A, int PASS>
-PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ itw, int tid) {
-    constexpr int aa = G::a(PASS);
-    constexpr int kb_lo = G::blo(PASS) - aa;
-    constexpr int kb_hi = G::bhi(PASS) - aa - (PASS == 0 ? 1 : 0);   // pass 0 ends with the N^-1 layer below
-    const int high = PASS == 0 ? 0 : (tid >> aa);
+PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T, const typename A::Tw *__restrict__ itw) {
+    using V = typename A::V;
+    using TwR = typename A::TwR;
+    constexpr int kb_hi = G::nl(PASS) - 1 - (PASS == 0 ? 1 : 0);   // pass 0 ends with the N^-1 layer below
 #pragma unroll
-    for (int kb = kb_lo; kb <= kb_hi; ++kb) {
-        const int m = 1 << (G::LOGN - 1 - (kb + aa));
-        const typename A::Tw *__restrict__ tp = itw + m + (high << (G::LOGR - 1 - kb));
+    for (int kb = 0; kb <= kb_hi; ++kb) {
 #pragma unroll
-        for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
-            const typename A::Tw t = tp[g];
+        for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
+            V ds[NBATCH];
+            TwR ts[NBATCH];
 #pragma unroll
-            for (int j = 0; j < (1 << kb); ++j) {
-                const int k0 = (g << (kb + 1)) | j, k1 = k0 | (1 << kb);
-                ar.inv_bfly(r[k0], r[k1], t);
+            for (int i = 0; i < NBATCH; ++i) {
+                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
+                ar.inv_split(r[k0], r[k0 | (1 << kb)], ds[i]);
+                ts[i] = ar.resolve(T.t[PassTw<G, A, PASS>::off(kb) + (b >> kb)]);
+            }
+            ar.template mul_tw_n<NBATCH>(ds, ts);
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) {
+                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
+                r[k0 | (1 << kb)] = ds[i];
             }
         }
     }
     if constexpr (PASS == 0) {                               // last layer: fold N^-1 in (SEAL does the same)
-        const typename A::Tw tn = itw[0], t = itw[1];
+        const TwR tn = ar.resolve(itw[0]), t = ar.resolve(itw[1]);
 #pragma unroll
-        for (int j = 0; j < G::R / 2; ++j) ar.inv_last(r[j], r[j + G::R / 2], tn, t);
+        for (int bb = 0; bb < G::R / 2; bb += NBATCH / 2) {
+            V vs[NBATCH];
+            TwR ts[NBATCH];
+#pragma unroll
+            for (int i = 0; i < NBATCH / 2; ++i) {
+                const int j = bb + i;
+                vs[2 * i] = r[j];
+                ar.inv_split(vs[2 * i], r[j + G::R / 2], vs[2 * i + 1]);
+                ts[2 * i] = tn; ts[2 * i + 1] = t;
+            }
+            ar.template mul_tw_n<NBATCH>(vs, ts);
+#pragma unroll
+            for (int i = 0; i < NBATCH / 2; ++i) { r[bb + i] = vs[2 * i]; r[bb + i + G::R / 2] = vs[2 * i + 1]; }
+        }
+    }
+}
+
+// element-wise helpers over the whole register file, in batches
+template <class G, class A>
+PF_HD void pass_reduce_all(typename A::V (&r)[G::R], const A &ar) {
+#pragma unroll
+    for (int bb = 0; bb < G::R; bb += 2 * NBATCH) {
+        typename A::V v[2 * NBATCH];
+#pragma unroll
+        for (int i = 0; i < 2 * NBATCH; ++i) v[i] = r[bb + i];
+        ar.template pass_reduce_n<2 * NBATCH>(v);
+#pragma unroll
+        for (int i = 0; i < 2 * NBATCH; ++i) r[bb + i] = v[i];
+    }
+}
+
+template <class G, class A>
+PF_HD void canon_all(typename A::V (&r)[G::R], const A &ar) {
+#pragma unroll
+    for (int bb = 0; bb < G::R; bb += 2 * NBATCH) {
+        typename A::V v[2 * NBATCH];
+#pragma unroll
+        for (int i = 0; i < 2 * NBATCH; ++i) v[i] = r[bb + i];
+        ar.template canon_n<2 * NBATCH>(v);
+#pragma unroll
+        for (int i = 0; i < 2 * NBATCH; ++i) r[bb + i] = v[i];
+    }
+}
+
+template <class G, class A, bool LAZY_IN>
+PF_HD void dyadic_all(typename A::V (&r)[G::R], const typename A::V (&pv)[G::R], const A &ar) {
+#pragma unroll
+    for (int bb = 0; bb < G::R; bb += NBATCH) {
+        typename A::V a[NBATCH], b[NBATCH];
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) { a[i] = r[bb + i]; b[i] = pv[bb + i]; }
+        if constexpr (LAZY_IN) ar.template for_dyadic_n<NBATCH>(a);
+        ar.template dyadic_n<NBATCH>(a, b);
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) r[bb + i] = a[i];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exchange through LDS.  `Sync` is a callable: s_barrier on the device, std::barrier in the simulator.
-// WR is the layout the registers are in, RD the layout they are wanted in.
+// Exchange through LDS between the layouts of two ADJACENT passes.  `Sync` is a callable: s_barrier on
+// the device, std::barrier in the simulator.  slot() is GF(2)-linear, so slot(base | koff) =
+// slot(base) ^ slot(koff) with the second factor a compile-time constant per register.
 // ------------------------------------------------------------------------------------------------
 template <class G, class V, int WR, int RD, class Sync>
 PF_HD void exchange(V (&r)[G::R], V *lds, int tid, Sync &&sync) {
-    constexpr int PS = WR > RD ? WR : RD;
-    const int bw = G::base(WR, tid), br = G::base(RD, tid);
+    static_assert(WR - RD == 1 || RD - WR == 1, "exchanges join adjacent passes");
+    constexpr int PAIR = WR < RD ? WR : RD;
+    const int sw = G::template slot<PAIR>(G::base(WR, tid)), sr = G::template slot<PAIR>(G::base(RD, tid));
     sync();                                   // previous readers of the buffer are done
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) lds[G::slot(PS, bw | (k << G::a(WR)))] = r[k];
+    for (int k = 0; k < G::R; ++k) lds[sw ^ G::template slot<PAIR>(G::koff(WR, k))] = r[k];
     sync();
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) r[k] = lds[G::slot(PS, br | (k << G::a(RD)))];
+    for (int k = 0; k < G::R; ++k) r[k] = lds[sr ^ G::template slot<PAIR>(G::koff(RD, k))];
 }
 
 // ------------------------------------------------------------------------------------------------
-// Whole-transform drivers (registers hold layout 0 on entry of fwd, layout 0 on exit of inv)
+// Whole-transform drivers: forward goes layout 0 -> layout LAST, inverse goes LAST -> 0
 // ------------------------------------------------------------------------------------------------
-// forward passes [0, P-1) with their exchanges: leaves the registers in the layout of the last pass,
-// that pass still to run (callers may issue independent loads in between)
-template <class G, class A, class Sync>
-PF_HD void fwd_head(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
-                    typename A::V *lds, int tid, Sync &&sync) {
-    if constexpr (G::P >= 2) { fwd_pass<G, A, 0>(r, ar, tw, tid); exchange<G, typename A::V, 0, 1>(r, lds, tid, sync); }
-    if constexpr (G::P >= 3) { fwd_pass<G, A, 1>(r, ar, tw, tid); exchange<G, typename A::V, 1, 2>(r, lds, tid, sync); }
-    if constexpr (G::P >= 4) { fwd_pass<G, A, 2>(r, ar, tw, tid); exchange<G, typename A::V, 2, 3>(r, lds, tid, sync); }
+// Each pass's twiddles are requested before the exchange in front of it (when the register budget of the
+// arithmetic allows), so their latency overlaps the LDS round trip and the barriers.
+template <class G, class A, int WR, int RD, class Sync>
+PF_HD void xchg_and_load(typename A::V (&r)[G::R], PassTw<G, A, RD> &t, const typename A::Tw *__restrict__ tw,
+                         typename A::V *lds, int tid, Sync &&sync) {
+    if constexpr (A::PREFETCH_TW) t.load(tw, tid);
+    exchange<G, typename A::V, WR, RD>(r, lds, tid, sync);
+    if constexpr (!A::PREFETCH_TW) t.load(tw, tid);
 }
 
 template <class G, class A, class Sync>
 PF_HD void fwd_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
                    typename A::V *lds, int tid, Sync &&sync) {
-    fwd_head<G, A>(r, ar, tw, lds, tid, sync);
-    fwd_pass<G, A, G::P - 1>(r, ar, tw, tid);
+    { PassTw<G, A, 0> t0; t0.load(tw, tid); fwd_pass<G, A, 0>(r, ar, t0); }
+    if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 1>(r, ar, t); }
+    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 2>(r, ar, t); }
+    if constexpr (G::P >= 4) { PassTw<G, A, 3> t; xchg_and_load<G, A, 2, 3>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, t); }
 }
 
+// `tl` = twiddles of the first inverse pass (LAST), which the caller fetched ahead of time
 template <class G, class A, class Sync>
-PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ itw,
+PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, G::LAST> &tl, const typename A::Tw *__restrict__ itw,
                    typename A::V *lds, int tid, Sync &&sync) {
+    inv_pass<G, A, G::LAST>(r, ar, tl, itw);
     if constexpr (G::P >= 4) {
-        inv_pass<G, A, 3>(r, ar, itw, tid);
-#pragma unroll
-        for (int k = 0; k < G::R; ++k) ar.pass_reduce(r[k]);
-        exchange<G, typename A::V, 3, 2>(r, lds, tid, sync);
+        PassTw<G, A, 2> t;
+        pass_reduce_all<G, A>(r, ar);
+        xchg_and_load<G, A, 3, 2>(r, t, itw, lds, tid, sync);
+        inv_pass<G, A, 2>(r, ar, t, itw);
     }
     if constexpr (G::P >= 3) {
-        inv_pass<G, A, 2>(r, ar, itw, tid);
-#pragma unroll
-        for (int k = 0; k < G::R; ++k) ar.pass_reduce(r[k]);
-        exchange<G, typename A::V, 2, 1>(r, lds, tid, sync);
+        PassTw<G, A, 1> t;
+        pass_reduce_all<G, A>(r, ar);
+        xchg_and_load<G, A, 2, 1>(r, t, itw, lds, tid, sync);
+        inv_pass<G, A, 1>(r, ar, t, itw);
     }
     if constexpr (G::P >= 2) {
-        inv_pass<G, A, 1>(r, ar, itw, tid);
-#pragma unroll
-        for (int k = 0; k < G::R; ++k) ar.pass_reduce(r[k]);
-        exchange<G, typename A::V, 1, 0>(r, lds, tid, sync);
+        PassTw<G, A, 0> t;
+        pass_reduce_all<G, A>(r, ar);
+        xchg_and_load<G, A, 1, 0>(r, t, itw, lds, tid, sync);
+        inv_pass<G, A, 0>(r, ar, t, itw);
     }
-    inv_pass<G, A, 0>(r, ar, itw, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernels bodies.  Global data is always read/written in layout 0 (lane-contiguous, coalesced).
+// Global memory access.  Layout 0: register k <-> coefficient k*T + tid (8 B per lane, lane-contiguous).
+// Layout LAST: runs of 2^nl coefficients per lane, 16 B per access when the run allows.
 // ------------------------------------------------------------------------------------------------
-enum : int { CTPT_ACCUMULATE = 1, CTPT_IN_NTT = 2, CTPT_OUT_NTT = 4 };
-
 template <class G, class A>
 PF_HD void load_l0(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) r[k] = A::from_u64((src + (k << G::a(0)))[tid]);
+    for (int k = 0; k < G::R; ++k) r[k] = A::from_u64((src + G::koff(0, k))[tid]);
 }
 
-// forward NTT of one limb-polynomial, in place or out of place
+template <class G, class A>
+PF_HD void load_last(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
+    constexpr int L = G::LAST, NL = G::nl(L);
+    const int b = G::base(L, tid);
+    if constexpr (NL >= 1) {
+#pragma unroll
+        for (int k = 0; k < G::R; k += 2) {
+            const U64x2 v = *reinterpret_cast<const U64x2 *>(src + G::koff(L, k) + b);
+            r[k] = A::from_u64(v.x); r[k + 1] = A::from_u64(v.y);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) r[k] = A::from_u64(src[G::koff(L, k) + b]);
+    }
+}
+
+template <class G>
+PF_HD void store_last(const uint64_t (&o)[G::R], uint64_t *dst, int tid) {
+    constexpr int L = G::LAST, NL = G::nl(L);
+    const int b = G::base(L, tid);
+    if constexpr (NL >= 1) {
+#pragma unroll
+        for (int k = 0; k < G::R; k += 2) *reinterpret_cast<U64x2 *>(dst + G::koff(L, k) + b) = U64x2{o[k], o[k + 1]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) dst[G::koff(L, k) + b] = o[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel bodies
+// ------------------------------------------------------------------------------------------------
+enum : int { CTPT_ACCUMULATE = 1, CTPT_IN_NTT = 2, CTPT_OUT_NTT = 4 };
+
+// forward NTT of one limb-polynomial: natural-order coefficients in, bit-reversed evaluations out
 template <class G, class A, class Sync>
 PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, const uint64_t *src,
                         uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0<G, A>(r, src, tid);
     fwd_all<G, A>(r, ar, tw, lds, tid, sync);
-    if constexpr (G::P >= 2) exchange<G, typename A::V, G::P - 1, 0>(r, lds, tid, sync);
+    canon_all<G, A>(r, ar);
+    uint64_t o[G::R];
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) (dst + (k << G::a(0)))[tid] = A::to_u64(ar.canon(r[k]));
+    for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
+    store_last<G>(o, dst, tid);
 }
 
 template <class G, class A, class Sync>
 PF_HD void body_ntt_inv(const A &ar, const typename A::Tw *__restrict__ itw, const uint64_t *src,
                         uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
-    load_l0<G, A>(r, src, tid);
-    if constexpr (G::P >= 2) exchange<G, typename A::V, 0, G::P - 1>(r, lds, tid, sync);
-    inv_all<G, A>(r, ar, itw, lds, tid, sync);
+    PassTw<G, A, G::LAST> tl;
+    tl.load(itw, tid);
+    load_last<G, A>(r, src, tid);
+    inv_all<G, A>(r, ar, tl, itw, lds, tid, sync);
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) (dst + (k << G::a(0)))[tid] = A::to_u64(ar.canon_small(r[k]));
+    for (int k = 0; k < G::R; ++k) (dst + G::koff(0, k))[tid] = A::to_u64(ar.canon_small(r[k]));
 }
 
 // ct x pt for one limb-polynomial: [NTT] -> dyadic with pt (NTT form) -> [INTT] -> [+= out]
@@ -333,52 +533,39 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
                      const uint64_t *ct, const uint64_t *pt, uint64_t *out,
                      typename A::V *lds, int tid, Sync &&sync) {
     using V = typename A::V;
-    constexpr int LAST = G::P - 1;
-    V r[G::R];
-    load_l0<G, A>(r, ct, tid);
-    V pv[G::R];
+    V r[G::R], pv[G::R];
+    PassTw<G, A, G::LAST> tl;                 // twiddles of the first inverse pass, requested with the plaintext
     if constexpr (FLAGS & CTPT_IN_NTT) {
-        load_l0<G, A>(pv, pt, tid);
-#pragma unroll
-        for (int k = 0; k < G::R; ++k) r[k] = ar.dyadic(r[k], pv[k]);
-        if constexpr (FLAGS & CTPT_OUT_NTT) {
-#pragma unroll
-            for (int k = 0; k < G::R; ++k) {
-                V v = ar.canon_small(r[k]);
-                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
-                (out + (k << G::a(0)))[tid] = A::to_u64(v);
-            }
-            return;
-        }
-        if constexpr (G::P >= 2) exchange<G, V, 0, LAST>(r, lds, tid, sync);
+        load_last<G, A>(r, ct, tid);
+        load_last<G, A>(pv, pt, tid);
+        dyadic_all<G, A, false>(r, pv, ar);
+        if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);
     } else {
+        load_l0<G, A>(r, ct, tid);
         fwd_all<G, A>(r, ar, tw, lds, tid, sync);
-        // fetch the plaintext limb (coalesced, layout 0) and move it into the layout the forward
-        // transform ended in.  Issued here rather than earlier: together with a pass's hoisted
-        // twiddles 64 more live VGPRs spill at the 256-register budget of 2 workgroups per CU.
-        PF_SCHED_FENCE();
-        load_l0<G, A>(pv, pt, tid);
-        if constexpr (G::P >= 2) exchange<G, V, 0, LAST>(pv, lds, tid, sync);
-        PF_SCHED_FENCE();
-#pragma unroll
-        for (int k = 0; k < G::R; ++k) r[k] = ar.dyadic(ar.for_dyadic(r[k]), pv[k]);
-        if constexpr (FLAGS & CTPT_OUT_NTT) {
-            if constexpr (G::P >= 2) exchange<G, V, LAST, 0>(r, lds, tid, sync);
-#pragma unroll
-            for (int k = 0; k < G::R; ++k) {
-                V v = ar.canon_small(r[k]);
-                if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
-                (out + (k << G::a(0)))[tid] = A::to_u64(v);
-            }
-            return;
-        }
+        // the plaintext limb is read in the layout the forward transform ended in: lane-contiguous from HBM
+        load_last<G, A>(pv, pt, tid);
+        dyadic_all<G, A, true>(r, pv, ar);
+        if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);
     }
-    inv_all<G, A>(r, ar, itw, lds, tid, sync);
+    if constexpr (FLAGS & CTPT_OUT_NTT) {
+        uint64_t o[G::R];
+        if constexpr (FLAGS & CTPT_ACCUMULATE) load_last<G, A>(pv, out, tid);
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) {
+            V v = ar.canon_small(r[k]);
+            if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, pv[k]));
+            o[k] = A::to_u64(v);
+        }
+        store_last<G>(o, out, tid);
+        return;
+    }
+    inv_all<G, A>(r, ar, tl, itw, lds, tid, sync);
 #pragma unroll
     for (int k = 0; k < G::R; ++k) {
         V v = ar.canon_small(r[k]);
-        if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + (k << G::a(0)))[tid])));
-        (out + (k << G::a(0)))[tid] = A::to_u64(v);
+        if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + G::koff(0, k))[tid])));
+        (out + G::koff(0, k))[tid] = A::to_u64(v);
     }
 }
 

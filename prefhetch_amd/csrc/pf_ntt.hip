@@ -22,21 +22,32 @@ struct pf_ctx {
     int device = 0;
     uint32_t N = 0, L = 0, logn = 0;
     bool all_f64 = false, force_u64 = false;
+    int num_cus = 256;
     std::vector<LimbTables> tabs;
     LimbDev *d_limbs = nullptr;
-    void *d_tables = nullptr;       // all twiddle tables, 16-byte entries
+    void *d_tables = nullptr;       // all twiddle tables, one allocation
 };
 
 namespace {
 
 // op: 0 forward, 1 inverse, 2 ctpt
 pf_status dispatch_logn(const pf_ctx *c, int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s) {
+    // persistent grid: as many workgroups as the chip holds at once (LDS-limited: N*8 bytes each of 160 KiB per CU,
+    // at most 8), rounded down to a multiple of 8*L so each workgroup keeps one limb; never more than the work
+    size_t per_cu = (160u * 1024u) / ((size_t)c->N * 8u);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid_sz = per_cu * (size_t)c->num_cus;
+    const size_t quantum = 8 * (size_t)c->L;
+    if (grid_sz > quantum) grid_sz -= grid_sz % quantum;
+    if (grid_sz > n) grid_sz = n;
+    const unsigned grid = (unsigned)grid_sz;
     switch (c->logn) {
-        case 10: launch_logn_10(arith, op, flags, a, n, s); break;
-        case 11: launch_logn_11(arith, op, flags, a, n, s); break;
-        case 12: launch_logn_12(arith, op, flags, a, n, s); break;
-        case 13: launch_logn_13(arith, op, flags, a, n, s); break;
-        case 14: launch_logn_14(arith, op, flags, a, n, s); break;
+        case 10: launch_logn_10(arith, op, flags, a, grid, s); break;
+        case 11: launch_logn_11(arith, op, flags, a, grid, s); break;
+        case 12: launch_logn_12(arith, op, flags, a, grid, s); break;
+        case 13: launch_logn_13(arith, op, flags, a, grid, s); break;
+        case 14: launch_logn_14(arith, op, flags, a, grid, s); break;
         default: return fail(PF_ERR_UNSUPPORTED, "ring degree not built (supported: 1024..16384)");
     }
     PF_HIP(hipGetLastError());
@@ -146,6 +157,10 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
     PF_GUARD(device);
     pf_ctx *c = new pf_ctx;
     c->device = device; c->N = N; c->L = L; c->logn = logn;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     c->tabs.resize(L);
     c->all_f64 = true;
     for (uint32_t l = 0; l < L; ++l) {
@@ -154,12 +169,16 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
         c->all_f64 = c->all_f64 && c->tabs[l].f64_ok;
     }
     std::vector<LimbDev> host(L);
-    static_assert(sizeof(TwU64) == 16 && sizeof(TwF64) == 16, "table entries are 16 bytes");
-    std::vector<TwU64> blob;                       // raw 16-byte entries; FP64 images are bit-copied in
-    auto append_u = [&](const std::vector<TwU64> &v) { const uint32_t off = (uint32_t)blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
+    static_assert(sizeof(TwU64) == 16 && sizeof(TwF64) == 8, "table entry sizes");
+    std::vector<uint64_t> blob;                    // 8-byte words; u64 tables start on even words (16-byte aligned)
+    auto append_u = [&](const std::vector<TwU64> &v) {
+        const uint32_t off = (uint32_t)blob.size();
+        for (const TwU64 &t : v) { blob.push_back(t.w); blob.push_back(t.wq); }
+        return off;
+    };
     auto append_f = [&](const std::vector<TwF64> &v) {
         const uint32_t off = (uint32_t)blob.size();
-        for (const TwF64 &t : v) blob.push_back(TwU64{__builtin_bit_cast(uint64_t, t.w), __builtin_bit_cast(uint64_t, t.wq)});
+        for (const TwF64 &t : v) blob.push_back(__builtin_bit_cast(uint64_t, t.w));
         return off;
     };
     for (uint32_t l = 0; l < L; ++l) {
@@ -171,8 +190,8 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
         d.fwd_u = append_u(t.fwd_u); d.inv_u = append_u(t.inv_u);
         if (t.f64_ok) { d.fwd_f = append_f(t.fwd_f); d.inv_f = append_f(t.inv_f); }
     }
-    if (hipMalloc(&c->d_tables, blob.size() * sizeof(TwU64)) != hipSuccess ||
-        hipMemcpy(c->d_tables, blob.data(), blob.size() * sizeof(TwU64), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc(&c->d_tables, blob.size() * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(c->d_tables, blob.data(), blob.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
         pf_ctx_destroy(c);
         return fail(PF_ERR_HIP, "uploading twiddle tables failed");
     }
@@ -205,13 +224,13 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
 
 pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, n, c->L, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
 pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, n, c->L, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
 
@@ -226,7 +245,7 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
     if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
-    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, c->L, pt_count == 1 ? 1u : 0u};
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, B * 2 * (size_t)c->L, c->L, pt_count == 1 ? 1u : 0u};
     return run_ntt_like(c, 2, flags, a, B * 2 * (size_t)c->L, stream);
 }
 

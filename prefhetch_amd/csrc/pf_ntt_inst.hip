@@ -11,8 +11,8 @@ namespace pf {
 namespace {
 
 template <int LOGN, class A>
-void launch_family(int op, int flags, const NttArgs &a, size_t n, hipStream_t s) {
-    const dim3 grid((unsigned)n), block(Geo<LOGN>::T);
+void launch_family(int op, int flags, const NttArgs &a, unsigned nblocks, hipStream_t s) {
+    const dim3 grid(nblocks), block(Geo<LOGN>::T);
     if (op == 0) { hipLaunchKernelGGL((k_ntt<LOGN, A, false>), grid, block, 0, s, a); return; }
     if (op == 1) { hipLaunchKernelGGL((k_ntt<LOGN, A, true>), grid, block, 0, s, a); return; }
     switch (flags & 7) {
@@ -24,9 +24,9 @@ void launch_family(int op, int flags, const NttArgs &a, size_t n, hipStream_t s)
 
 }  // namespace
 
-void PF_CAT(launch_logn_, PF_INST_LOGN)(int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s) {
-    if (arith == 0) launch_family<PF_INST_LOGN, ArithF64>(op, flags, a, n, s);
-    else launch_family<PF_INST_LOGN, ArithU64>(op, flags, a, n, s);
+void PF_CAT(launch_logn_, PF_INST_LOGN)(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s) {
+    if (arith == 0) launch_family<PF_INST_LOGN, ArithF64>(op, flags, a, grid, s);
+    else launch_family<PF_INST_LOGN, ArithU64>(op, flags, a, grid, s);
 }
 
 }  // namespace pf

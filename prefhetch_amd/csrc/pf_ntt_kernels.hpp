@@ -8,12 +8,12 @@
 namespace pf {
 
 // Per-limb constants in HBM; a workgroup reads its limb's entry through the scalar cache.
-// Twiddle tables are addressed as 16-byte-entry offsets from ONE kernel-argument base pointer, so the
+// Twiddle tables are addressed as 8-byte-word offsets from ONE kernel-argument base pointer, so the
 // loads are global_/s_load (a pointer fetched from memory would make them flat_load).
 struct LimbDev {
     uint64_t q, two_q, ratio0, ratio1;
     double qd, qinv;
-    uint32_t fwd_u, inv_u, fwd_f, inv_f;     // entry offsets into NttArgs::tables
+    uint32_t fwd_u, inv_u, fwd_f, inv_f;     // word offsets into NttArgs::tables (u64 tables 16-byte aligned)
 };
 
 struct NttArgs {
@@ -22,6 +22,7 @@ struct NttArgs {
     const uint64_t *src;
     uint64_t *dst;
     const uint64_t *pt;
+    size_t n_polys;
     uint32_t L;
     uint32_t pt_broadcast;
 };
@@ -29,44 +30,50 @@ struct NttArgs {
 template <class A> struct ArithOf;
 template <> struct ArithOf<ArithF64> {
     static __device__ __forceinline__ ArithF64 make(const LimbDev &l) { return ArithF64{l.qd, l.qinv}; }
-    static __device__ __forceinline__ const TwF64 *fwd(const void *t, const LimbDev &l) { return static_cast<const TwF64 *>(t) + l.fwd_f; }
-    static __device__ __forceinline__ const TwF64 *inv(const void *t, const LimbDev &l) { return static_cast<const TwF64 *>(t) + l.inv_f; }
+    static __device__ __forceinline__ const TwF64 *fwd(const void *t, const LimbDev &l) { return reinterpret_cast<const TwF64 *>(static_cast<const uint64_t *>(t) + l.fwd_f); }
+    static __device__ __forceinline__ const TwF64 *inv(const void *t, const LimbDev &l) { return reinterpret_cast<const TwF64 *>(static_cast<const uint64_t *>(t) + l.inv_f); }
 };
 template <> struct ArithOf<ArithU64> {
     static __device__ __forceinline__ ArithU64 make(const LimbDev &l) { return ArithU64{l.q, l.two_q, l.ratio0, l.ratio1}; }
-    static __device__ __forceinline__ const TwU64 *fwd(const void *t, const LimbDev &l) { return static_cast<const TwU64 *>(t) + l.fwd_u; }
-    static __device__ __forceinline__ const TwU64 *inv(const void *t, const LimbDev &l) { return static_cast<const TwU64 *>(t) + l.inv_u; }
+    static __device__ __forceinline__ const TwU64 *fwd(const void *t, const LimbDev &l) { return reinterpret_cast<const TwU64 *>(static_cast<const uint64_t *>(t) + l.fwd_u); }
+    static __device__ __forceinline__ const TwU64 *inv(const void *t, const LimbDev &l) { return reinterpret_cast<const TwU64 *>(static_cast<const uint64_t *>(t) + l.inv_u); }
 };
 
 struct WgSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 
-// One workgroup = one limb-polynomial.  INVERSE selects the direction at compile time.
+// Persistent workgroups: the grid is sized to the chip (2 workgroups per CU at N = 8192) and every workgroup
+// walks limb-polynomials blockIdx.x, blockIdx.x + gridDim.x, ...  The grid size is a multiple of 8 * L where
+// possible, so a workgroup (and its XCD, under round-robin placement) keeps one limb: its twiddle tables stay
+// in that XCD's L2.  Removes the per-workgroup dispatch gap (64 KiB of LDS has to drain before the next
+// workgroup can start) that rocprof showed between back-to-back one-shot workgroups.
 template <int LOGN, class A, bool INVERSE>
-__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ntt(NttArgs p) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, (Geo<LOGN>::T >= 512 ? 4 : 2)) k_ntt(NttArgs p) {
     using G = Geo<LOGN>;
     __shared__ typename A::V lds[G::N];
-    const size_t poly = blockIdx.x;
-    const LimbDev &lm = p.limbs[poly % p.L];
-    const A ar = ArithOf<A>::make(lm);
-    const uint64_t *src = p.src + poly * G::N;
-    uint64_t *dst = p.dst + poly * G::N;
-    if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
-    else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+    for (size_t poly = blockIdx.x; poly < p.n_polys; poly += gridDim.x) {
+        const LimbDev &lm = p.limbs[poly % p.L];
+        const A ar = ArithOf<A>::make(lm);
+        const uint64_t *src = p.src + poly * G::N;
+        uint64_t *dst = p.dst + poly * G::N;
+        if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+        else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+    }
 }
 
-// Fused ct x pt: block b handles limb-polynomial b of the ciphertext batch [B][2][L][N].
+// Fused ct x pt: limb-polynomial `poly` of the ciphertext batch [B][2][L][N].
 template <int LOGN, class A, int FLAGS>
-__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ctpt(NttArgs p) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, (Geo<LOGN>::T >= 512 ? 4 : 2)) k_ctpt(NttArgs p) {
     using G = Geo<LOGN>;
     __shared__ typename A::V lds[G::N];
-    const size_t poly = blockIdx.x;
-    const uint32_t limb = (uint32_t)(poly % p.L);
-    const size_t ctidx = poly / (2 * (size_t)p.L);
-    const LimbDev &lm = p.limbs[limb];
-    const A ar = ArithOf<A>::make(lm);
-    const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
-    body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt, p.dst + poly * G::N,
-                           lds, (int)threadIdx.x, WgSync{});
+    for (size_t poly = blockIdx.x; poly < p.n_polys; poly += gridDim.x) {
+        const uint32_t limb = (uint32_t)(poly % p.L);
+        const size_t ctidx = poly / (2 * (size_t)p.L);
+        const LimbDev &lm = p.limbs[limb];
+        const A ar = ArithOf<A>::make(lm);
+        const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
+        body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt,
+                               p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
+    }
 }
 
 // Element-wise kernels: 24 B (dyadic/add/sub) or 16 B (negate) of HBM traffic per coefficient, HBM-bound.
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(256) k_elementwise(EwArgs p) {
 namespace pf {
 // Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64;
 // op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`.
-#define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s);
+#define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
 PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14)
 #undef PF_DECL_LAUNCH
 }  // namespace pf

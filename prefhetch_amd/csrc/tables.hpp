@@ -42,7 +42,7 @@ struct LimbTables {
     uint64_t ratio0 = 0, ratio1 = 0;              // floor(2^128/q)
     bool f64_ok = false;                          // q small enough for the exact-FP64 back-end
     std::vector<TwU64> fwd_u, inv_u;              // N entries each, entry 0 of inv_u = N^-1, entry 1 = psi^-bitrev(1)*N^-1
-    std::vector<TwF64> fwd_f, inv_f;
+    std::vector<TwF64> fwd_f, inv_f;              // the same twiddles as doubles (8 bytes per entry)
 };
 
 // Bound for ArithF64 (see ntt_core.hpp): 32*q <= 2^50 and (1+LOGN)*q <= 2^50.
@@ -90,10 +90,9 @@ inline bool build_limb_tables(uint32_t N, uint64_t q, LimbTables &t, std::string
     t.fwd_f.clear(); t.inv_f.clear();
     if (t.f64_ok) {
         t.fwd_f.resize(N); t.inv_f.resize(N);
-        const double qd = (double)q;
         for (uint32_t j = 0; j < N; ++j) {
-            t.fwd_f[j] = TwF64{(double)fw[j], (double)fw[j] / qd};
-            t.inv_f[j] = TwF64{(double)iw[j], (double)iw[j] / qd};
+            t.fwd_f[j] = TwF64{(double)fw[j]};
+            t.inv_f[j] = TwF64{(double)iw[j]};
         }
     }
     return true;

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Runs ONE hot-path kernel a few times on synthetic BASELINE config-3 data (for rocprofv3 --pmc / --kernel-trace).
+usage: python3 tools/run_kernel.py {ctpt|ntt_fwd|ntt_inv|dyadic|flat} [reps] [batch]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import prefhetch_amd as pf  # noqa: E402
+
+MODULI = [0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001]
+N = 8192
+what = sys.argv[1] if len(sys.argv) > 1 else "ctpt"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(1)
+if what == "flat":
+    xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
+    xq = torch.randint(0, 256, (B, 128), generator=g, device=dev, dtype=torch.int32).float()
+    idx = pf.FlatL2(xb, dev)
+    for _ in range(reps):
+        idx.search(xq, 200)
+else:
+    ctx = pf.RnsContext(N, MODULI, dev)
+    if len(sys.argv) > 4 and sys.argv[4] == "u64":
+        ctx.force_u64(True)
+    ct = torch.stack([torch.randint(0, q, (B, 2, N), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=2).contiguous()
+    pt = torch.stack([torch.randint(0, q, (B, N), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=1).contiguous()
+    out = torch.empty_like(ct)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.ct_pt_mul(ct, pt, out=out)
+    e0.record()
+    for _ in range(reps):
+        if what == "ctpt":
+            ctx.ct_pt_mul(ct, pt, out=out)
+        elif what == "ntt_fwd":
+            ctx.ntt_forward_(ct)
+        elif what == "ntt_inv":
+            ctx.ntt_inverse_(ct)
+        elif what == "dyadic":
+            ctx.dyadic_mul(ct, out, out=out)
+if what != "flat":
+    e1.record()
+torch.cuda.synchronize()
+if what != "flat":
+    ms = e0.elapsed_time(e1) / reps
+    per = {"ctpt": 40, "ntt_fwd": 32, "ntt_inv": 32, "dyadic": 48}[what] * 4 * N * B
+    print("%s: %.4f ms/launch  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (what, ms, per / ms / 1e6, per / ms / 1e6 / 80))
+print("done", what, reps, B)
