@@ -36,7 +36,12 @@
 #define PF_HD __device__ __forceinline__
 // keeps hipcc's scheduler from re-serialising the batched arithmetic below
 #define PF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// distinct asm statements (compiler memory barriers) at both ends of two sibling branches keep LLVM from
+// sinking/hoisting their common LDS accesses into one block that picks the REGISTER by a pointer phi -- which
+// would demote the register-file array to scratch memory
+#define PF_BRANCH_TAG(s) asm volatile("; " s ::: "memory")
 #else
+#define PF_BRANCH_TAG(s) ((void)0)
 #define PF_HD inline
 #define PF_SCHED_FENCE() ((void)0)
 #endif
@@ -82,7 +87,20 @@ struct Geo {
     static constexpr int koff(int p, int k) {
         return ((k >> nl(p)) << (LOGN - nh(p))) | ((k & ((1 << nl(p)) - 1)) << a(p));
     }
+    // Thread-id placement.  Passes before the last: the low a(p) id bits sit below the thread-local field, the
+    // rest above it.  Last pass: the id fills the bits between the low run and the carried top bits in order,
+    // except that its MOST SIGNIFICANT bit sits at YBIT, the index bit that is the register MSB of the pass
+    // before -- so that across every exchange "top register bit" and "top thread-id bit" swap roles (what the
+    // two-round half-buffer exchange below relies on) while lanes 0..2^y-1 still cover one contiguous run.
+    static constexpr int TB = LOGN - LOGR;                        // thread-id bits
+    static constexpr int YBIT = P >= 2 ? a(P - 2 < 0 ? 0 : P - 2) + LOGR - 1 : 0;
     static PF_HD int base(int p, int tid) {
+        if (p == P - 1 && P >= 2) {
+            constexpr int NL = nl(P - 1), y = YBIT - NL;
+            const int msb = tid >> (TB - 1), lo = tid & ((1 << (TB - 1)) - 1);
+            const int field = ((lo >> y) << (y + 1)) | (msb << y) | (lo & ((1 << y) - 1));
+            return field << NL;
+        }
         const int aa = a(p);
         const int low = tid & ((1 << aa) - 1), high = tid >> aa;
         return (high << (aa + nl(p))) | low;
@@ -119,6 +137,7 @@ struct ArithF64 {
     using Tw = TwF64;
     using TwR = TwF64R;
     static constexpr bool PREFETCH_TW = true;      // 8-byte twiddles: a whole pass's worth fits in registers across an exchange
+    static constexpr bool HALF_EXCHANGE_OK = true; // fits the 168-VGPR budget of three workgroups per CU
     double q, qinv;
 
     static PF_HD V from_u64(uint64_t x) {            // x < 2^52 : set exponent of 2^52, subtract
@@ -199,6 +218,7 @@ struct ArithU64 {
     using Tw = TwU64;
     using TwR = TwU64;
     static constexpr bool PREFETCH_TW = false;     // 16-byte twiddles: fetched after the exchange (register budget)
+    static constexpr bool HALF_EXCHANGE_OK = false; // 64-bit integer butterflies need the 256-VGPR budget: two workgroups per CU
     uint64_t q, two_q, ratio0, ratio1;               // ratio = floor(2^128/q)
 
     static PF_HD V from_u64(uint64_t x) { return x; }
@@ -290,6 +310,7 @@ PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
         for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
             V ys[NBATCH];
             TwR ts[NBATCH];
+            PF_SCHED_FENCE();                 // keeps the twiddle resolves (w * 1/q) of later batches from piling up in registers
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
@@ -317,6 +338,7 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
         for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
             V ds[NBATCH];
             TwR ts[NBATCH];
+            PF_SCHED_FENCE();
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
@@ -397,17 +419,76 @@ PF_HD void dyadic_all(typename A::V (&r)[G::R], const typename A::V (&pv)[G::R],
 // the device, std::barrier in the simulator.  slot() is GF(2)-linear, so slot(base | koff) =
 // slot(base) ^ slot(koff) with the second factor a compile-time constant per register.
 // ------------------------------------------------------------------------------------------------
-template <class G, class V, int WR, int RD, class Sync>
-PF_HD void exchange(V (&r)[G::R], V *lds, int tid, Sync &&sync) {
+#ifndef PF_HALF_EXCHANGE
+#define PF_HALF_EXCHANGE 1     // exchange through an N/2-entry LDS buffer in two rounds: 32 KiB per workgroup at N = 8192
+#endif
+
+template <class G, class A>
+struct Xchg {
+    // Across every exchange of a 3-pass transform the top register bit of one side is the top thread-id bit of
+    // the other (index bits LOGN-1 and YBIT).  Seen over those two bits an exchange is a 2x2 block transpose:
+    // round 0 moves the off-diagonal blocks, round 1 the diagonal ones; in each round a thread writes one half
+    // of its registers and reads the same half back, so N/2 LDS entries suffice and three workgroups instead of
+    // two fit a CU's 160 KiB.  The thread's half is wave-uniform (T >= 128), so the register choice is a scalar
+    // branch, not a per-lane select.
+    static constexpr bool HALF = PF_HALF_EXCHANGE && A::HALF_EXCHANGE_OK && G::P == 3 && G::nh(G::LAST) >= 1 && G::T >= 128;
+    static constexpr int LDS_ENTRIES = HALF ? G::N / 2 : G::N;
+};
+
+#if defined(__HIPCC__)
+PF_HD int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+PF_HD int wave_uniform(int v) { return v; }
+#endif
+
+// one round of the half-buffer exchange: every thread writes register half `sel` and reads the same half back
+template <class G, class A, int WR, int RD, class Sync>
+PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, int sw, int sr, int sel, Sync &&sync) {
+    constexpr int PAIR = WR < RD ? WR : RD;
+    constexpr int M = G::N / 2 - 1, H = G::R / 2;                 // LDS position = slot with the top index bit dropped
+    sync();
+    if (sel) {
+        PF_BRANCH_TAG("upper half: write");
+#pragma unroll
+        for (int j = 0; j < H; ++j) lds[(sw ^ G::template slot<PAIR>(G::koff(WR, H + j))) & M] = r[H + j];
+        PF_BRANCH_TAG("upper half: written");
+    } else {
+        PF_BRANCH_TAG("lower half: write");
+#pragma unroll
+        for (int j = 0; j < H; ++j) lds[(sw ^ G::template slot<PAIR>(G::koff(WR, j))) & M] = r[j];
+        PF_BRANCH_TAG("lower half: written");
+    }
+    sync();
+    if (sel) {
+        PF_BRANCH_TAG("upper half: read");
+#pragma unroll
+        for (int j = 0; j < H; ++j) r[H + j] = lds[(sr ^ G::template slot<PAIR>(G::koff(RD, H + j))) & M];
+        PF_BRANCH_TAG("upper half: read done");
+    } else {
+        PF_BRANCH_TAG("lower half: read");
+#pragma unroll
+        for (int j = 0; j < H; ++j) r[j] = lds[(sr ^ G::template slot<PAIR>(G::koff(RD, j))) & M];
+        PF_BRANCH_TAG("lower half: read done");
+    }
+}
+
+template <class G, class A, int WR, int RD, class Sync>
+PF_HD void exchange(typename A::V (&r)[G::R], typename A::V *lds, int tid, Sync &&sync) {
     static_assert(WR - RD == 1 || RD - WR == 1, "exchanges join adjacent passes");
     constexpr int PAIR = WR < RD ? WR : RD;
     const int sw = G::template slot<PAIR>(G::base(WR, tid)), sr = G::template slot<PAIR>(G::base(RD, tid));
-    sync();                                   // previous readers of the buffer are done
+    if constexpr (!Xchg<G, A>::HALF) {
+        sync();                                   // previous readers of the buffer are done
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) lds[sw ^ G::template slot<PAIR>(G::koff(WR, k))] = r[k];
-    sync();
+        for (int k = 0; k < G::R; ++k) lds[sw ^ G::template slot<PAIR>(G::koff(WR, k))] = r[k];
+        sync();
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) r[k] = lds[sr ^ G::template slot<PAIR>(G::koff(RD, k))];
+        for (int k = 0; k < G::R; ++k) r[k] = lds[sr ^ G::template slot<PAIR>(G::koff(RD, k))];
+    } else {
+        const int t = wave_uniform(tid >> (G::TB - 1));           // this thread's half (top thread-id bit)
+        half_round<G, A, WR, RD>(r, lds, sw, sr, t ^ 1, sync);    // off-diagonal blocks
+        half_round<G, A, WR, RD>(r, lds, sw, sr, t, sync);        // diagonal blocks
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,9 +499,10 @@ PF_HD void exchange(V (&r)[G::R], V *lds, int tid, Sync &&sync) {
 template <class G, class A, int WR, int RD, class Sync>
 PF_HD void xchg_and_load(typename A::V (&r)[G::R], PassTw<G, A, RD> &t, const typename A::Tw *__restrict__ tw,
                          typename A::V *lds, int tid, Sync &&sync) {
-    if constexpr (A::PREFETCH_TW) t.load(tw, tid);
-    exchange<G, typename A::V, WR, RD>(r, lds, tid, sync);
-    if constexpr (!A::PREFETCH_TW) t.load(tw, tid);
+    constexpr bool early = A::PREFETCH_TW && !Xchg<G, A>::HALF;   // at three workgroups per CU the registers go to occupancy instead
+    if constexpr (early) t.load(tw, tid);
+    exchange<G, A, WR, RD>(r, lds, tid, sync);
+    if constexpr (!early) t.load(tw, tid);
 }
 
 template <class G, class A, class Sync>

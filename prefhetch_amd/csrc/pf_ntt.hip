@@ -32,16 +32,7 @@ namespace {
 
 // op: 0 forward, 1 inverse, 2 ctpt
 pf_status dispatch_logn(const pf_ctx *c, int arith, int op, int flags, const NttArgs &a, size_t n, hipStream_t s) {
-    // persistent grid: as many workgroups as the chip holds at once (LDS-limited: N*8 bytes each of 160 KiB per CU,
-    // at most 8), rounded down to a multiple of 8*L so each workgroup keeps one limb; never more than the work
-    size_t per_cu = (160u * 1024u) / ((size_t)c->N * 8u);
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    size_t grid_sz = per_cu * (size_t)c->num_cus;
-    const size_t quantum = 8 * (size_t)c->L;
-    if (grid_sz > quantum) grid_sz -= grid_sz % quantum;
-    if (grid_sz > n) grid_sz = n;
-    const unsigned grid = (unsigned)grid_sz;
+    const unsigned grid = (unsigned)n;          // one workgroup per limb-polynomial
     switch (c->logn) {
         case 10: launch_logn_10(arith, op, flags, a, grid, s); break;
         case 11: launch_logn_11(arith, op, flags, a, grid, s); break;
@@ -224,13 +215,13 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
 
 pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, n, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
 pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, n, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
 
@@ -245,7 +236,7 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
     if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
-    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, B * 2 * (size_t)c->L, c->L, pt_count == 1 ? 1u : 0u};
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, c->L, pt_count == 1 ? 1u : 0u};
     return run_ntt_like(c, 2, flags, a, B * 2 * (size_t)c->L, stream);
 }
 

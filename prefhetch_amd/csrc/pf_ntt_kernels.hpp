@@ -22,7 +22,6 @@ struct NttArgs {
     const uint64_t *src;
     uint64_t *dst;
     const uint64_t *pt;
-    size_t n_polys;
     uint32_t L;
     uint32_t pt_broadcast;
 };
@@ -39,41 +38,43 @@ template <> struct ArithOf<ArithU64> {
     static __device__ __forceinline__ const TwU64 *inv(const void *t, const LimbDev &l) { return reinterpret_cast<const TwU64 *>(static_cast<const uint64_t *>(t) + l.inv_u); }
 };
 
+// waves per SIMD the kernels are register-budgeted for: workgroups per CU (LDS-limited, at most 3) x waves per
+// workgroup / 4 SIMDs, at least 2
+#define PF_WG_PER_CU(LOGN, A) ((160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8) > 3 ? 3 : (160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8))
+#define PF_WAVES_PER_SIMD(LOGN, A) ((PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256) < 2 ? 2 : (PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256))
+
 struct WgSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 
-// Persistent workgroups: the grid is sized to the chip (2 workgroups per CU at N = 8192) and every workgroup
-// walks limb-polynomials blockIdx.x, blockIdx.x + gridDim.x, ...  The grid size is a multiple of 8 * L where
-// possible, so a workgroup (and its XCD, under round-robin placement) keeps one limb: its twiddle tables stay
-// in that XCD's L2.  Removes the per-workgroup dispatch gap (64 KiB of LDS has to drain before the next
-// workgroup can start) that rocprof showed between back-to-back one-shot workgroups.
+// One workgroup = one limb-polynomial (blockIdx.x).  Consecutive block ids cycle through the limbs, and blocks
+// b and b+8 share an XCD under round-robin placement, so for L | 8 an XCD's L2 only ever holds one or two limbs'
+// twiddle tables.  (A persistent-workgroup loop was measured: no gain -- dispatch is not the bottleneck -- and
+// its loop-invariant LDS/global addresses, hoisted by hipcc, cost ~80 VGPRs.)
 template <int LOGN, class A, bool INVERSE>
-__global__ void __launch_bounds__(Geo<LOGN>::T, (Geo<LOGN>::T >= 512 ? 4 : 2)) k_ntt(NttArgs p) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ntt(NttArgs p) {
     using G = Geo<LOGN>;
-    __shared__ typename A::V lds[G::N];
-    for (size_t poly = blockIdx.x; poly < p.n_polys; poly += gridDim.x) {
-        const LimbDev &lm = p.limbs[poly % p.L];
-        const A ar = ArithOf<A>::make(lm);
-        const uint64_t *src = p.src + poly * G::N;
-        uint64_t *dst = p.dst + poly * G::N;
-        if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
-        else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
-    }
+    __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    const size_t poly = blockIdx.x;
+    const LimbDev &lm = p.limbs[poly % p.L];
+    const A ar = ArithOf<A>::make(lm);
+    const uint64_t *src = p.src + poly * G::N;
+    uint64_t *dst = p.dst + poly * G::N;
+    if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+    else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
 }
 
-// Fused ct x pt: limb-polynomial `poly` of the ciphertext batch [B][2][L][N].
+// Fused ct x pt: limb-polynomial blockIdx.x of the ciphertext batch [B][2][L][N].
 template <int LOGN, class A, int FLAGS>
-__global__ void __launch_bounds__(Geo<LOGN>::T, (Geo<LOGN>::T >= 512 ? 4 : 2)) k_ctpt(NttArgs p) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ctpt(NttArgs p) {
     using G = Geo<LOGN>;
-    __shared__ typename A::V lds[G::N];
-    for (size_t poly = blockIdx.x; poly < p.n_polys; poly += gridDim.x) {
-        const uint32_t limb = (uint32_t)(poly % p.L);
-        const size_t ctidx = poly / (2 * (size_t)p.L);
-        const LimbDev &lm = p.limbs[limb];
-        const A ar = ArithOf<A>::make(lm);
-        const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
-        body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt,
-                               p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
-    }
+    __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    const size_t poly = blockIdx.x;
+    const uint32_t limb = (uint32_t)(poly % p.L);
+    const size_t ctidx = poly / (2 * (size_t)p.L);
+    const LimbDev &lm = p.limbs[limb];
+    const A ar = ArithOf<A>::make(lm);
+    const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
+    body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt,
+                           p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
 }
 
 // Element-wise kernels: 24 B (dyadic/add/sub) or 16 B (negate) of HBM traffic per coefficient, HBM-bound.

@@ -14,7 +14,7 @@ using namespace pf;
 
 template <class G, class A, class Body>
 static void run_wg(Body &&body) {
-    std::vector<typename A::V> lds(G::N);
+    std::vector<typename A::V> lds(Xchg<G, A>::LDS_ENTRIES);
     std::barrier bar(G::T);
     std::vector<std::thread> th;
     th.reserve(G::T);
