@@ -53,6 +53,21 @@ struct TwF64 { double w; };            // table entry of the FP64 back-end: the 
 struct TwF64R { double w, wq; };       // ... resolved on load: wq = fl(w * fl(1/q))
 struct alignas(16) U64x2 { uint64_t x, y; };
 
+// Load through the CONSTANT address space: the twiddle tables are never written while a kernel runs, and a
+// uniform constant-space load becomes an s_load even after a barrier (a global-space load behind the barrier's
+// fence is no longer provably unclobbered, so hipcc would issue it once per lane into VGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+PF_HD T const_load(const T *p) {               // T = double or uint64_t
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+#else
+template <class T>
+PF_HD T const_load(const T *p) { return *p; }
+#endif
+PF_HD TwF64 const_load_tw(const TwF64 *p) { return TwF64{const_load(&p->w)}; }
+PF_HD TwU64 const_load_tw(const TwU64 *p) { return TwU64{const_load(&p->w), const_load(&p->wq)}; }
+
 PF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 PF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 
@@ -146,7 +161,9 @@ struct ArithF64 {
     static PF_HD uint64_t to_u64(V v) {              // 0 <= v < 2^51, integer valued
         return d2u(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
     }
+    static constexpr bool WQ0_TABLE = true;        // table entries N .. N+R-1 hold fl(w/q) of entries 0 .. R-1
     PF_HD TwR resolve(Tw t) const { return TwR{t.w, t.w * qinv}; }
+    static PF_HD TwR with_quotient(Tw t, double wq) { return TwR{t.w, wq}; }
     template <int NB>
     PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {     // y[i] <- y[i]*t[i] (mod q), |.| < q
         double h[NB], l[NB], c[NB];
@@ -223,7 +240,9 @@ struct ArithU64 {
 
     static PF_HD V from_u64(uint64_t x) { return x; }
     static PF_HD uint64_t to_u64(V v) { return v; }
+    static constexpr bool WQ0_TABLE = false;
     PF_HD TwR resolve(Tw t) const { return t; }
+    static PF_HD TwR with_quotient(Tw t, double) { return t; }
     PF_HD V guard(V v) const { return v >= two_q ? v - two_q : v; }
     template <int NB>
     PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {
@@ -285,7 +304,11 @@ struct PassTw {
     static constexpr int NL = G::nl(PASS);
     static constexpr int off(int kb) { int o = 0; for (int j = 0; j < kb; ++j) o += G::R >> (j + 1); return o; }
     static constexpr int COUNT = off(NL);
+    // Pass 0's twiddles (table entries 1 .. R-1) are workgroup-uniform and arrive through the scalar cache; for the
+    // FP64 back-end their quotients fl(w/q) are tabulated too (entries N .. N+R-1), so resolving them costs no VALU.
+    static constexpr bool TABULATED_WQ = PASS == 0 && A::WQ0_TABLE;
     typename A::Tw t[COUNT];
+    double wq[TABULATED_WQ ? COUNT : 1];
 
     PF_HD void load(const typename A::Tw *__restrict__ tw, int tid) {
         constexpr int aa = G::a(PASS);
@@ -293,10 +316,19 @@ struct PassTw {
 #pragma unroll
         for (int kb = 0; kb < NL; ++kb) {
             const int sh = aa + kb + 1;
-            const typename A::Tw *__restrict__ tp = tw + (1 << (G::LOGN - sh)) + (tb >> sh);
+            const int lane_idx = tb >> sh;                        // per-lane part; the rest of the address is workgroup-uniform
 #pragma unroll
-            for (int g = 0; g < (G::R >> (kb + 1)); ++g) t[off(kb) + g] = tp[G::koff(PASS, g << (kb + 1)) >> sh];
+            for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
+                const int idx = (1 << (G::LOGN - sh)) + (G::koff(PASS, g << (kb + 1)) >> sh);
+                if constexpr (PASS == 0) t[off(kb) + g] = const_load_tw(tw + idx);
+                else t[off(kb) + g] = (tw + idx)[lane_idx];
+                if constexpr (TABULATED_WQ) wq[off(kb) + g] = const_load(reinterpret_cast<const double *>(tw) + G::N + idx);
+            }
         }
+    }
+    PF_HD typename A::TwR get(const A &ar, int i) const {
+        if constexpr (TABULATED_WQ) return A::with_quotient(t[i], wq[i]);
+        else return ar.resolve(t[i]);
     }
 };
 
@@ -315,7 +347,7 @@ PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
                 ys[i] = r[k0 | (1 << kb)];
-                ts[i] = ar.resolve(T.t[PassTw<G, A, PASS>::off(kb) + (b >> kb)]);
+                ts[i] = T.get(ar, PassTw<G, A, PASS>::off(kb) + (b >> kb));
             }
             ar.template mul_tw_n<NBATCH>(ys, ts);
 #pragma unroll
@@ -343,7 +375,7 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
                 ar.inv_split(r[k0], r[k0 | (1 << kb)], ds[i]);
-                ts[i] = ar.resolve(T.t[PassTw<G, A, PASS>::off(kb) + (b >> kb)]);
+                ts[i] = T.get(ar, PassTw<G, A, PASS>::off(kb) + (b >> kb));
             }
             ar.template mul_tw_n<NBATCH>(ds, ts);
 #pragma unroll
@@ -354,7 +386,8 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
         }
     }
     if constexpr (PASS == 0) {                               // last layer: fold N^-1 in (SEAL does the same)
-        const TwR tn = ar.resolve(itw[0]), t = ar.resolve(itw[1]);
+        const TwR tn = A::WQ0_TABLE ? A::with_quotient(const_load_tw(itw), const_load(reinterpret_cast<const double *>(itw) + G::N)) : ar.resolve(const_load_tw(itw));
+        const TwR t = A::WQ0_TABLE ? A::with_quotient(const_load_tw(itw + 1), const_load(reinterpret_cast<const double *>(itw) + G::N + 1)) : ar.resolve(const_load_tw(itw + 1));
 #pragma unroll
         for (int bb = 0; bb < G::R / 2; bb += NBATCH / 2) {
             V vs[NBATCH];
@@ -374,16 +407,20 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
 }
 
 // element-wise helpers over the whole register file, in batches
-template <class G, class A>
+// Re-centre after inverse pass PASS.  Registers whose last transformed local bit is set came straight out of a
+// modular product (|v| < q) and are left alone; the other half accumulated sums.
+template <class G, class A, int PASS>
 PF_HD void pass_reduce_all(typename A::V (&r)[G::R], const A &ar) {
+    constexpr int TOP = 1 << (G::nl(PASS) - 1);
+    constexpr int NB2 = 2 * NBATCH;
 #pragma unroll
-    for (int bb = 0; bb < G::R; bb += 2 * NBATCH) {
-        typename A::V v[2 * NBATCH];
+    for (int bb = 0; bb < G::R / 2; bb += NB2) {
+        typename A::V v[NB2];
 #pragma unroll
-        for (int i = 0; i < 2 * NBATCH; ++i) v[i] = r[bb + i];
-        ar.template pass_reduce_n<2 * NBATCH>(v);
+        for (int i = 0; i < NB2; ++i) { const int c = bb + i; v[i] = r[((c / TOP) * 2 * TOP) | (c % TOP)]; }
+        ar.template pass_reduce_n<NB2>(v);
 #pragma unroll
-        for (int i = 0; i < 2 * NBATCH; ++i) r[bb + i] = v[i];
+        for (int i = 0; i < NB2; ++i) { const int c = bb + i; r[((c / TOP) * 2 * TOP) | (c % TOP)] = v[i]; }
     }
 }
 
@@ -441,33 +478,50 @@ PF_HD int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PF_HD int wave_uniform(int v) { return v; }
 #endif
 
+// LDS addressing of one side (layout SIDE) of exchange PAIR.  slot() is GF(2)-linear and only rewrites the low
+// five bits, so for register k:  position = (slot(base) ^ c_k) + khi_k, with c_k < 32 a compile-time constant
+// taking few distinct values and khi_k the (compile-time) high part of koff -- i.e. a handful of base registers
+// plus the 16-bit immediate offset of ds_read/ds_write, instead of one XOR per access.
+template <class G, int PAIR, int SIDE, int MASK>
+struct XchgAddr {
+    int v[32];                                 // slot(base) ^ c for every c; unused entries are dead code
+    PF_HD explicit XchgAddr(int tid) {
+        const int sb = G::template slot<PAIR>(G::base(SIDE, tid)) & MASK;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = sb ^ c;
+    }
+    static constexpr int ck(int k) { return G::template slot<PAIR>(G::koff(SIDE, k) & 31) ^ (G::template slot<PAIR>(G::koff(SIDE, k) & ~31) & 31); }
+    static constexpr int khi(int k) { return G::koff(SIDE, k) & ~31 & MASK; }
+    template <class V> PF_HD V *at(V *lds, int k) const { return lds + khi(k) + v[ck(k)]; }
+};
+
 // one round of the half-buffer exchange: every thread writes register half `sel` and reads the same half back
 template <class G, class A, int WR, int RD, class Sync>
-PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, int sw, int sr, int sel, Sync &&sync) {
-    constexpr int PAIR = WR < RD ? WR : RD;
-    constexpr int M = G::N / 2 - 1, H = G::R / 2;                 // LDS position = slot with the top index bit dropped
+PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAddr<G, (WR < RD ? WR : RD), WR, G::N / 2 - 1> &aw,
+                      const XchgAddr<G, (WR < RD ? WR : RD), RD, G::N / 2 - 1> &ard, int sel, Sync &&sync) {
+    constexpr int H = G::R / 2;
     sync();
     if (sel) {
         PF_BRANCH_TAG("upper half: write");
 #pragma unroll
-        for (int j = 0; j < H; ++j) lds[(sw ^ G::template slot<PAIR>(G::koff(WR, H + j))) & M] = r[H + j];
+        for (int j = 0; j < H; ++j) *aw.at(lds, H + j) = r[H + j];
         PF_BRANCH_TAG("upper half: written");
     } else {
         PF_BRANCH_TAG("lower half: write");
 #pragma unroll
-        for (int j = 0; j < H; ++j) lds[(sw ^ G::template slot<PAIR>(G::koff(WR, j))) & M] = r[j];
+        for (int j = 0; j < H; ++j) *aw.at(lds, j) = r[j];
         PF_BRANCH_TAG("lower half: written");
     }
     sync();
     if (sel) {
         PF_BRANCH_TAG("upper half: read");
 #pragma unroll
-        for (int j = 0; j < H; ++j) r[H + j] = lds[(sr ^ G::template slot<PAIR>(G::koff(RD, H + j))) & M];
+        for (int j = 0; j < H; ++j) r[H + j] = *ard.at(lds, H + j);
         PF_BRANCH_TAG("upper half: read done");
     } else {
         PF_BRANCH_TAG("lower half: read");
 #pragma unroll
-        for (int j = 0; j < H; ++j) r[j] = lds[(sr ^ G::template slot<PAIR>(G::koff(RD, j))) & M];
+        for (int j = 0; j < H; ++j) r[j] = *ard.at(lds, j);
         PF_BRANCH_TAG("lower half: read done");
     }
 }
@@ -476,18 +530,21 @@ template <class G, class A, int WR, int RD, class Sync>
 PF_HD void exchange(typename A::V (&r)[G::R], typename A::V *lds, int tid, Sync &&sync) {
     static_assert(WR - RD == 1 || RD - WR == 1, "exchanges join adjacent passes");
     constexpr int PAIR = WR < RD ? WR : RD;
-    const int sw = G::template slot<PAIR>(G::base(WR, tid)), sr = G::template slot<PAIR>(G::base(RD, tid));
     if constexpr (!Xchg<G, A>::HALF) {
+        const XchgAddr<G, PAIR, WR, G::N - 1> aw(tid);
+        const XchgAddr<G, PAIR, RD, G::N - 1> ard(tid);
         sync();                                   // previous readers of the buffer are done
 #pragma unroll
-        for (int k = 0; k < G::R; ++k) lds[sw ^ G::template slot<PAIR>(G::koff(WR, k))] = r[k];
+        for (int k = 0; k < G::R; ++k) *aw.at(lds, k) = r[k];
         sync();
 #pragma unroll
-        for (int k = 0; k < G::R; ++k) r[k] = lds[sr ^ G::template slot<PAIR>(G::koff(RD, k))];
+        for (int k = 0; k < G::R; ++k) r[k] = *ard.at(lds, k);
     } else {
+        const XchgAddr<G, PAIR, WR, G::N / 2 - 1> aw(tid);       // LDS position = slot with the top index bit dropped
+        const XchgAddr<G, PAIR, RD, G::N / 2 - 1> ard(tid);
         const int t = wave_uniform(tid >> (G::TB - 1));           // this thread's half (top thread-id bit)
-        half_round<G, A, WR, RD>(r, lds, sw, sr, t ^ 1, sync);    // off-diagonal blocks
-        half_round<G, A, WR, RD>(r, lds, sw, sr, t, sync);        // diagonal blocks
+        half_round<G, A, WR, RD>(r, lds, aw, ard, t ^ 1, sync);   // off-diagonal blocks
+        half_round<G, A, WR, RD>(r, lds, aw, ard, t, sync);       // diagonal blocks
     }
 }
 
@@ -521,19 +578,19 @@ PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, G::
     inv_pass<G, A, G::LAST>(r, ar, tl, itw);
     if constexpr (G::P >= 4) {
         PassTw<G, A, 2> t;
-        pass_reduce_all<G, A>(r, ar);
+        pass_reduce_all<G, A, 3>(r, ar);
         xchg_and_load<G, A, 3, 2>(r, t, itw, lds, tid, sync);
         inv_pass<G, A, 2>(r, ar, t, itw);
     }
     if constexpr (G::P >= 3) {
         PassTw<G, A, 1> t;
-        pass_reduce_all<G, A>(r, ar);
+        pass_reduce_all<G, A, 2>(r, ar);
         xchg_and_load<G, A, 2, 1>(r, t, itw, lds, tid, sync);
         inv_pass<G, A, 1>(r, ar, t, itw);
     }
     if constexpr (G::P >= 2) {
         PassTw<G, A, 0> t;
-        pass_reduce_all<G, A>(r, ar);
+        pass_reduce_all<G, A, 1>(r, ar);
         xchg_and_load<G, A, 1, 0>(r, t, itw, lds, tid, sync);
         inv_pass<G, A, 0>(r, ar, t, itw);
     }
