@@ -1,0 +1,63 @@
+// server_lib.h -- class Server, the drop-in boundary of the PreFHEtch server
+// (/root/reference/include/server/server_lib.h:12-50).  Public names, signatures and constness are the
+// reference's, so src/server/controllers/Query.cc:15-18,48-51,86-88,116-117 and src/server/server.cpp:9-11
+// compile against this header unchanged.  What differs is behind the pimpl: the faiss objects are replaced
+// by handles of libprefhetch_hip.so (include/prefhetch_hip.h) -- the base matrix and the centroids live in
+// MI355X HBM and every distance stage runs as a HIP kernel.
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "client_server_utils.h"
+
+// The reference spells some index types faiss::idx_t (server_lib.h:33,36,41) and others faiss_idx_t;
+// both are int64_t.  faiss itself is not a dependency of this build.
+namespace faiss {
+using idx_t = int64_t;
+}
+
+class Server {
+  private:
+    struct Impl;                       // device handles, stream, staging buffers (src: prefhetch_amd/csrc/server_lib.cpp)
+    std::unique_ptr<Impl> m_Impl;
+
+  public:
+    Server();
+    ~Server();
+    // Singleton for static access across all controllers (reference :20-23)
+    static std::shared_ptr<Server> &getInstance() {
+        static std::shared_ptr<Server> server = std::make_shared<Server>();
+        return server;
+    }
+
+    // Loads ../sift/siftsmall/siftsmall_base.fvecs into HBM and the IVF centroids from the cache file next to it
+    // (reference src/server/server_lib.cpp:55-99).  Training the IVFPQ index is not part of this build: when no
+    // centroid cache exists this throws std::runtime_error, as the reference does for an unusable index file.
+    void init_index();
+    // Serves the four routes through Drogon when built with -DPREFHETCH_WITH_DROGON; otherwise throws.
+    void run_webserver();
+
+    void retrieve_centroids(std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> &centroids) const;
+    void coarseSearch(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
+                      const std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> &nearest_centroid_idx,
+                      std::vector<float> &coarse_distance_scores, std::vector<faiss::idx_t> &coarse_distance_indexes,
+                      std::array<size_t, NQUERY> &list_sizes_per_query) const;
+    void preciseSearch(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
+                       const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &nearest_coarse_vector_idx,
+                       std::array<std::array<float, COARSE_PROBE>, NQUERY> &precise_distance_scores) const;
+    void preciseVectorPIR(const std::array<std::array<faiss_idx_t, K>, NQUERY> &k_nearest_precise_vectors_idx,
+                          std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY> &query_results);
+
+    // ---- additions of this build (not in the reference) ---------------------------------------------------
+    // Installs base vectors [nb][128] and centroids [nlist][128] from host memory instead of the dataset files.
+    void init_from_memory(const float *base, size_t nb, const float *centroids, size_t nlist, int device = 0);
+    // The executed flat-L2 shortlist of the protocol (client sort_nearest_centroids, src/client/client_lib.cpp:50-81)
+    // on the server's IndexFlatL2 over the centroids: top-NPROBE centroid ids (and squared distances) per query.
+    void nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
+                          std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> &nearest_centroid_idx,
+                          std::array<std::array<float, NPROBE>, NQUERY> &nearest_centroid_dist) const;
+};

@@ -1,0 +1,122 @@
+// test_server.cpp -- exercises class Server (the reference's own interface, include/server/server_lib.h) on a
+// real GPU with the reference's shapes (NBASE=10000, NQUERY=5, COARSE_PROBE=200, K=100, NLIST=256) and checks
+// every output against literal restatements of the reference loops (src/server/server_lib.cpp:140-196,
+// src/client/client_lib.cpp:50-81).  Also pins the public signatures to the reference's at compile time.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <type_traits>
+
+#include "../../include/server/server_lib.h"
+
+// ---- signature pins (reference include/server/server_lib.h:19-49) ----
+using Q = std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY>;
+static_assert(std::is_same_v<decltype(&Server::getInstance), std::shared_ptr<Server> &(*)()>);
+static_assert(std::is_same_v<decltype(&Server::init_index), void (Server::*)()>);
+static_assert(std::is_same_v<decltype(&Server::run_webserver), void (Server::*)()>);
+static_assert(std::is_same_v<decltype(&Server::retrieve_centroids), void (Server::*)(std::vector<std::array<float, 128>> &) const>);
+static_assert(std::is_same_v<decltype(&Server::coarseSearch),
+                             void (Server::*)(const Q &, const std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> &, std::vector<float> &,
+                                              std::vector<faiss::idx_t> &, std::array<size_t, NQUERY> &) const>);
+static_assert(std::is_same_v<decltype(&Server::preciseSearch),
+                             void (Server::*)(const Q &, const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &,
+                                              std::array<std::array<float, COARSE_PROBE>, NQUERY> &) const>);
+static_assert(std::is_same_v<decltype(&Server::preciseVectorPIR),
+                             void (Server::*)(const std::array<std::array<faiss_idx_t, K>, NQUERY> &,
+                                              std::array<std::array<std::array<float, 128>, K>, NQUERY> &)>);
+static_assert(PRECISE_VECTOR_DIMENSIONS == 128 && NPROBE == 20 && COARSE_PROBE == 200 && K == 100 && NBASE == 10000 &&
+              NQUERY == 5 && NLIST == 256 && SUB_QUANTIZERS == 32 && SUB_QUANTIZER_SIZE == 8);
+
+static int fails = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++fails; } } while (0)
+
+int main(int argc, char **argv) {
+    const bool gaussian = argc > 1 && std::string(argv[1]) == "gaussian";
+    std::mt19937 rng(20250801);
+    std::uniform_int_distribution<int> pix(0, 255);
+    std::normal_distribution<float> gauss(0.f, 1.f);
+    auto draw = [&] { return gaussian ? gauss(rng) : static_cast<float>(pix(rng)); };
+    std::vector<float> base(static_cast<size_t>(NBASE) * 128), cent(static_cast<size_t>(NLIST) * 128);
+    for (float &v : base) v = draw();
+    for (float &v : cent) v = draw();
+    auto &srv = Server::getInstance();
+    EXPECT(srv.get() == Server::getInstance().get());
+    bool threw = false;
+    try { std::vector<std::array<float, 128>> c; srv->retrieve_centroids(c); } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw);                                   // not initialised yet -> runtime_error, like an unusable index in the reference
+    srv->init_from_memory(base.data(), NBASE, cent.data(), NLIST);
+
+    Q query;
+    for (auto &q : query) for (float &v : q) v = draw();
+
+    // retrieve_centroids: server_lib.cpp:101-109
+    std::vector<std::array<float, 128>> got_c;
+    srv->retrieve_centroids(got_c);
+    EXPECT(got_c.size() == static_cast<size_t>(NLIST));
+    EXPECT(std::memcmp(got_c.data(), cent.data(), cent.size() * 4) == 0);
+
+    // preciseSearch: literal restatement of server_lib.cpp:151-164
+    std::uniform_int_distribution<int64_t> pick(0, NBASE - 1);
+    std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> ids;
+    for (auto &row : ids) for (auto &v : row) v = pick(rng);
+    std::array<std::array<float, COARSE_PROBE>, NQUERY> got_d, ref_d;
+    srv->preciseSearch(query, ids, got_d);
+    for (int i = 0; i < NQUERY; i++)
+        for (int j = 0; j < COARSE_PROBE; j++) {
+            float dist = 0.0;
+            const float *row = base.data() + ids[i][j] * PRECISE_VECTOR_DIMENSIONS;
+            for (int k = 0; k < PRECISE_VECTOR_DIMENSIONS; k++) dist += std::pow((row[k] - query[i][k]), 2);
+            ref_d[i][j] = dist;
+        }
+    EXPECT(std::memcmp(got_d.data(), ref_d.data(), sizeof got_d) == 0);      // bit-exact, also on gaussian data
+
+    // preciseVectorPIR: server_lib.cpp:169-196
+    std::array<std::array<faiss_idx_t, K>, NQUERY> kid;
+    for (auto &row : kid) for (auto &v : row) v = pick(rng);
+    auto res = std::make_unique<std::array<std::array<std::array<float, 128>, K>, NQUERY>>();
+    srv->preciseVectorPIR(kid, *res);
+    for (int i = 0; i < NQUERY; i++)
+        for (int j = 0; j < K; j++) EXPECT(std::memcmp((*res)[i][j].data(), base.data() + kid[i][j] * 128, 512) == 0);
+
+    // nearestCentroids == client sort_nearest_centroids (client_lib.cpp:50-81) truncated to NPROBE
+    std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> cid;
+    std::array<std::array<float, NPROBE>, NQUERY> cdist;
+    srv->nearestCentroids(query, cid, cdist);
+    for (int i = 0; i < NQUERY; i++) {
+        std::vector<std::pair<float, int64_t>> all;
+        for (int j = 0; j < NLIST; j++) {
+            float distance = 0.0;
+            for (int k = 0; k < 128; k++) distance += std::pow(query[i][k] - cent[j * 128 + k], 2);
+            all.push_back({distance, j});
+        }
+        std::sort(all.begin(), all.end());
+        for (int j = 0; j < NPROBE; j++) {
+            if (gaussian) {          // fp32 distances within 1e-5 relative (north_star); ids may swap only inside that band
+                EXPECT(std::fabs(cdist[i][j] - all[j].first) <= 1e-5f * all[j].first);
+            } else {
+                EXPECT(cid[i][j] == all[j].second);
+                EXPECT(cdist[i][j] == all[j].first);
+            }
+        }
+    }
+
+    // coarseSearch is a "next" row: must fail loudly, not return garbage
+    threw = false;
+    try {
+        std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> nc{};
+        std::vector<float> s; std::vector<faiss::idx_t> l; std::array<size_t, NQUERY> sz{};
+        srv->coarseSearch(query, nc, s, l, sz);
+    } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw);
+
+    Timer t; long long us = -1, ms = -1;
+    t.StartTimer(); t.StopTimer(); t.getDuration(us, ms);
+    EXPECT(us >= 0 && ms >= 0);
+    if (fails) std::printf("test_server: %d FAILURES\n", fails);
+    else std::printf("test_server: OK (%s data)\n", gaussian ? "gaussian" : "integer");
+    return fails ? 1 : 0;
+}

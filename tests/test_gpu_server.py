@@ -1,0 +1,18 @@
+"""GPU test of the C++ `Server` class (the reference's own interface) through the compiled test binary
+tests/cpp/test_server (built by __graft_entry__.build() / make -C prefhetch_amd/csrc)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "tests", "cpp", "test_server")
+
+
+@pytest.mark.parametrize("mode", ["integer", "gaussian"])
+def test_server_class_reference_shapes(mode):
+    assert os.path.exists(BIN), "tests/cpp/test_server missing: run __graft_entry__.build()"
+    r = subprocess.run([BIN] + ([mode] if mode == "gaussian" else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "test_server: OK" in r.stdout, r.stdout + r.stderr
