@@ -96,6 +96,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
 
     import prefhetch_amd as pf
+    from prefhetch_amd import dist as pfd
 
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(20250801 + 3 + 1000 * rank)
@@ -109,7 +110,7 @@ def main():
     flat = pf.FlatL2(xb, dev)
     flat.reserve(B, TOPK)
     del xb
-    gathered = torch.empty((world, B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
@@ -121,8 +122,7 @@ def main():
         ctx.ct_pt_mul(ct, pt, out=out)                             # stage B (one launch)
         if e: e[2].record()
         if world > 1:                                              # stage C: one collective, packed (I, D)
-            packed = torch.cat([I.view(torch.int32).view(B, TOPK, 2), D.view(torch.int32).unsqueeze(-1)], dim=-1).contiguous()
-            dist.all_gather_into_tensor(gathered, packed)
+            pfd.gather_topk(D, I, out=gathered)
         if e: e[3].record()
         return D, I
 
