@@ -8,12 +8,20 @@
 //   Server::preciseSearch                     /root/reference/src/server/server_lib.cpp:140-167
 //   Server::preciseVectorPIR / retrieve_centroids   server_lib.cpp:169-196 / 101-109
 //
-// Search = for each chunk of base rows: (1) k_l2_tile, an LDS-tiled fp32 distance tile kernel
-// (||x||^2 + ||y||^2 - 2 x.y, the decomposition faiss uses for nq >= 20, clamped at 0) on the f32
-// matrix pipe -- v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, so the result is
-// plain IEEE fp32 -- writing a [nq][chunk] slab that stays in the Infinity Cache; (2) k_select_chunk,
-// one workgroup per query keeping a reservoir (faiss ReservoirTopN does the same on the CPU for
-// k >= 100) of packed (distance bits, id) keys in LDS, compacted by a bitonic sort when it fills.
+// Search pipeline (all launches on the caller's stream, nothing synchronises):
+//   distances  k_l2_tile: LDS-tiled fp32 tiles of ||x||^2 + ||y||^2 - 2 x.y (the decomposition faiss uses for
+//              nq >= 20, clamped at 0) on the f32 matrix pipe -- v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered
+//              fmaf chain, so a distance is plain IEEE fp32 and can be recomputed exactly by scalar code.
+//   bootstrap  the first few thousand base rows go through a [nq][chunk] slab and k_select (one workgroup per
+//              query keeping a reservoir of packed (distance bits, id) keys in LDS, compacted by a bitonic sort
+//              when it fills -- faiss ReservoirTopN does the same on the CPU for k >= 100).  This yields each
+//              query's running top-k and its k-th distance tau.
+//   streaming  the rest of the base is processed in geometrically growing chunks whose tile kernel FILTERS in its
+//              epilogue: only distances <= tau are appended (one atomic per survivor) to the query's candidate
+//              list -- expected k * chunk / rows_seen survivors -- and k_select merges them into the running
+//              top-k and tightens tau.  No distance slab is written or re-read.  If a candidate list overflows
+//              (adversarial row order), k_select re-derives that query's chunk exactly by recomputing the
+//              distances with the same fmaf chain: slower, never wrong.
 // Keys order by (distance, id), which fixes the tie order faiss leaves undefined.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -47,8 +55,12 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
 // accumulator register covers 32 consecutive floats of one query's slab row.
 struct TileArgs {
     const float *xq; const float *xb; const float *qn; const float *bn;
-    float *slab;            // [nq][slab_ld]
+    float *slab;            // [nq][slab_ld]                         (FILTER == false)
     uint32_t nq, d; size_t nb_first, nb_count; uint32_t slab_ld;
+    const float *tau;       // [nq] running k-th distance            (FILTER == true)
+    uint32_t *cand_cnt;     // [nq] survivors appended so far (may exceed cap: overflow marker)
+    uint64_t *cand;         // [nq][cap] packed keys
+    uint32_t cap;
 };
 
 __device__ __forceinline__ void stage_slab(float *lds, const float *__restrict__ src, size_t row0, size_t rows_valid,
@@ -77,6 +89,7 @@ __device__ __forceinline__ void stage_slab(float *lds, const float *__restrict__
     }
 }
 
+template <bool FILTER>
 __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
     __shared__ float sA[TK * LDA];
     __shared__ float sB[TK * LDA];
@@ -111,6 +124,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
         }
     }
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+    if constexpr (FILTER) {
+        // per-query norm and threshold of this tile's 128 rows, staged in LDS (sA is free now)
+        __syncthreads();
+        if (tid < TM) {
+            const bool ok = q0 + tid < p.nq;
+            sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
+            sA[TM + tid] = ok ? p.tau[q0 + tid] : -1.f;            // -1: nothing passes (distances are >= 0)
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const size_t col = c0 + wn + 32 * j + (lane & 31);
@@ -120,8 +143,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const size_t row = q0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (col_ok && row < p.nq) {
+                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const size_t row = q0 + lrow;
+                if constexpr (FILTER) {
+                    float dist = fmaf(-2.f, acc[i][j][r], sA[lrow] + bnv);
+                    dist = dist < 0.f ? 0.f : dist;
+                    if (col_ok && dist <= sA[TM + lrow]) {           // ties pass; k_select orders by (distance, id)
+                        const uint32_t pos = atomicAdd(&p.cand_cnt[row], 1u);
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col));
+                    }
+                } else if (col_ok && row < p.nq) {
                     float dist = fmaf(-2.f, acc[i][j][r], p.qn[row] + bnv);
                     dist = dist < 0.f ? 0.f : dist;
                     p.slab[row * p.slab_ld + col] = dist;
@@ -133,13 +164,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
 
 // ---- selection -----------------------------------------------------------------------------------
 struct SelArgs {
-    const float *slab; uint32_t slab_ld;
-    size_t nb_first, nb_count;      // ids of this chunk are nb_first + column
-    uint64_t *state;                // [nq][k] keys carried between chunks (ascending)
-    uint32_t *state_cnt;            // [nq]
+    const float *slab; uint32_t slab_ld;     // mode 0: distances of this chunk, [nq][slab_ld]
+    size_t nb_first, nb_count;               // ids of this chunk are nb_first + column
+    uint64_t *state;                         // [nq][k] keys carried between chunks (ascending)
+    uint32_t *state_cnt;                     // [nq]
+    float *tau;                              // [nq] k-th distance so far (+inf while fewer than k)
+    uint32_t *cand_cnt; const uint64_t *cand; uint32_t cap;   // mode 1: survivors of the filtered tile kernel
+    const float *xq, *xb, *qn, *bn; uint32_t d;                // mode 1 overflow fallback: exact recomputation
     uint32_t k;
-    int first, last;
-    float *D; int64_t *I;           // written when last
+    int mode, first, last;
+    float *D; int64_t *I;                    // written when last
 };
 
 // in-LDS bitonic sort of SEL_CAP keys, ascending
@@ -159,21 +193,12 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid) {
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(SEL_THREADS) k_select_chunk(SelArgs p) {
-    __shared__ uint64_t keys[SEL_CAP];
-    __shared__ uint32_t cnt;
-    __shared__ uint64_t tau;
-    const int tid = threadIdx.x;
-    const size_t q = blockIdx.x;
-    const uint32_t k = p.k;
-    // load carried state
-    const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
-    for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = i < c0 ? p.state[q * k + i] : KEY_INF;
-    if (tid == 0) { cnt = c0; tau = c0 == k ? p.state[q * k + k - 1] : KEY_INF; }
-    __syncthreads();
-    const float *row = p.slab + q * (size_t)p.slab_ld;
-    // rounds of 4 columns per thread: at most 1024 new keys per round, so compact when fewer remain
-    for (size_t base = 0; base < p.nb_count; base += SEL_THREADS * 4) {
+// Reservoir scan of columns [0, nb_count): `dist4(col, v)` yields the distances of columns col..col+3.
+// Rounds of 4 columns per thread add at most 1024 keys, so the reservoir is compacted when fewer slots remain.
+template <class Dist4>
+__device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, uint64_t &tau, uint32_t k, size_t nb_first,
+                                               size_t nb_count, int tid, Dist4 &&dist4) {
+    for (size_t base = 0; base < nb_count; base += SEL_THREADS * 4) {
         const uint32_t c = cnt;                               // stable here: a barrier separates it from every add
         __syncthreads();                                      // ... and everyone has read it before the next add
         if (c > SEL_CAP - SEL_THREADS * 4) {                  // workgroup-uniform
@@ -186,23 +211,65 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_chunk(SelArgs p) {
         const uint64_t t = tau;
         const size_t col = base + (size_t)tid * 4;
         float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-        if (col + 3 < p.nb_count && ((p.slab_ld & 3) == 0)) {
-            const float4 f = *reinterpret_cast<const float4 *>(row + col);
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
-        }
+        if (col < nb_count) dist4(col, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (col + e < p.nb_count) {
-                const uint64_t key = make_key(v[e], (uint32_t)(p.nb_first + col + e));
+            if (col + e < nb_count) {
+                const uint64_t key = make_key(v[e], (uint32_t)(nb_first + col + e));
                 if (key < t) { const uint32_t pos = atomicAdd(&cnt, 1u); keys[pos] = key; }
             }
         }
         __syncthreads();
     }
-    // end of chunk: sort, keep k, carry or emit
+}
+
+// One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
+// running top-k, or -- if the candidate list overflowed -- rescan the chunk exactly.
+__global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
+    __shared__ uint64_t keys[SEL_CAP];
+    __shared__ uint32_t cnt;
+    __shared__ uint64_t tau;
+    const int tid = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const uint32_t k = p.k;
+    const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
+    const uint32_t nc = p.mode == 1 ? p.cand_cnt[q] : 0u;
+    const bool merge = p.mode == 1 && nc <= p.cap;            // workgroup-uniform
+    for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) {
+        uint64_t v = KEY_INF;
+        if (i < c0) v = p.state[q * k + i];
+        else if (merge && i - c0 < nc) v = p.cand[q * p.cap + (i - c0)];     // c0 + nc <= k + cap <= SEL_CAP
+        keys[i] = v;
+    }
+    if (tid == 0) { cnt = merge ? c0 + nc : c0; tau = c0 == k ? p.state[q * k + k - 1] : KEY_INF; }
+    __syncthreads();
+    if (p.mode == 0) {
+        const float *row = p.slab + q * (size_t)p.slab_ld;
+        const bool vec = (p.slab_ld & 3) == 0;
+        reservoir_scan(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[4]) {
+            if (vec && col + 3 < p.nb_count) {
+                const float4 f = *reinterpret_cast<const float4 *>(row + col);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
+            }
+        });
+    } else if (!merge) {
+        // overflow: the same k-ordered fmaf chain the matrix pipe evaluates, one base row at a time
+        const float *x = p.xq + q * (size_t)p.d;
+        const float qn = p.qn[q];
+        reservoir_scan(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[4]) {
+            for (int e = 0; e < 4; ++e) {
+                if (col + e >= p.nb_count) break;
+                const float *y = p.xb + (p.nb_first + col + e) * (size_t)p.d;
+                float acc = 0.f;
+                for (uint32_t t = 0; t < p.d; ++t) acc = fmaf(x[t], y[t], acc);
+                const float dist = fmaf(-2.f, acc, qn + p.bn[p.nb_first + col + e]);
+                v[e] = dist < 0.f ? 0.f : dist;
+            }
+        });
+    }
+    // sort, keep k, carry or emit
     bitonic_sort(keys, tid);
     const uint32_t total = cnt < k ? cnt : k;
     if (p.last) {
@@ -214,7 +281,11 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_chunk(SelArgs p) {
         }
     } else {
         for (uint32_t i = tid; i < total; i += SEL_THREADS) p.state[q * k + i] = keys[i];
-        if (tid == 0) p.state_cnt[q] = total;
+        if (tid == 0) {
+            p.state_cnt[q] = total;
+            p.tau[q] = total == k ? __uint_as_float((uint32_t)(keys[k - 1] >> 32)) : INFINITY;
+            p.cand_cnt[q] = 0;
+        }
     }
 }
 
@@ -274,30 +345,32 @@ struct pf_flat {
 
 namespace {
 
-struct WsPlan { size_t chunk, slab_ld, off_qn, off_state, off_cnt, off_slab, total; };
+constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
+constexpr size_t MAX_CHUNK = 262144;       // largest streaming chunk
+
+struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, total; };
 
 WsPlan plan_ws(size_t nb, size_t nq, uint32_t k) {
     WsPlan w{};
-    // slab of about 64 MiB (Infinity-Cache resident), a multiple of the tile width
-    size_t chunk = (64ull << 20) / (nq * 4);
-    chunk = chunk / 1024 * 1024;
-    if (chunk < 1024) chunk = 1024;
     const size_t nb_pad = (nb + 127) / 128 * 128;
-    if (chunk > nb_pad) chunk = nb_pad;
-    w.chunk = chunk; w.slab_ld = chunk;
+    w.boot = BOOT_ROWS < nb_pad ? BOOT_ROWS : (nb_pad ? nb_pad : 128);
+    w.slab_ld = w.boot;
+    w.cap = SEL_CAP - k;                    // state (<= k keys) + candidates fit one sort
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    w.off_qn = 0;
-    w.off_state = up(nq * 4);
-    w.off_cnt = w.off_state + up(nq * (size_t)k * 8);
-    w.off_slab = w.off_cnt + up(nq * 4);
-    w.total = w.off_slab + up(nq * chunk * 4);
+    size_t o = 0;
+    w.off_qn = o; o += up(nq * 4);
+    w.off_tau = o; o += up(nq * 4);
+    w.off_cnt = o; o += up(nq * 4);
+    w.off_scnt = o; o += up(nq * 4);
+    w.off_state = o; o += up(nq * (size_t)k * 8);
+    w.off_cand = o; o += up(nq * w.cap * 8);
+    w.off_slab = o; o += up(nq * w.slab_ld * 4);
+    w.total = o;
     return w;
 }
 
 pf_status ensure_ws(pf_flat *f, size_t bytes) {
     if (bytes <= f->ws_bytes) return PF_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)cs;
     if (f->ws) { PF_HIP(hipFree(f->ws)); f->ws = nullptr; f->ws_bytes = 0; }
     PF_HIP(hipMalloc(&f->ws, bytes));
     f->ws_bytes = bytes;
@@ -369,21 +442,40 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     if (st != PF_OK) return st;
     char *base = static_cast<char *>(f->ws);
     float *qn = reinterpret_cast<float *>(base + w.off_qn);
+    float *tau = reinterpret_cast<float *>(base + w.off_tau);
+    uint32_t *ccnt = reinterpret_cast<uint32_t *>(base + w.off_cnt);
+    uint32_t *scnt = reinterpret_cast<uint32_t *>(base + w.off_scnt);
     uint64_t *state = reinterpret_cast<uint64_t *>(base + w.off_state);
-    uint32_t *scnt = reinterpret_cast<uint32_t *>(base + w.off_cnt);
+    uint64_t *cand = reinterpret_cast<uint64_t *>(base + w.off_cand);
     float *slab = reinterpret_cast<float *>(base + w.off_slab);
     hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
-    const size_t n_chunks = f->nb ? (f->nb + w.chunk - 1) / w.chunk : 1;
-    for (size_t ci = 0; ci < n_chunks; ++ci) {
-        const size_t first = ci * w.chunk;
-        const size_t count = f->nb ? (f->nb - first < w.chunk ? f->nb - first : w.chunk) : 0;
-        if (count) {
-            TileArgs t{xq, f->xb, qn, f->bn, slab, (uint32_t)nq, f->d, first, count, (uint32_t)w.slab_ld};
-            const dim3 grid((unsigned)((count + TN - 1) / TN), (unsigned)((nq + TM - 1) / TM));
-            hipLaunchKernelGGL(k_l2_tile, grid, dim3(256), 0, s, t);
-        }
-        SelArgs a{slab, (uint32_t)w.slab_ld, first, count, state, scnt, k, ci == 0, ci + 1 == n_chunks, D, I};
-        hipLaunchKernelGGL(k_select_chunk, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+    TileArgs t{};
+    t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
+    t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
+    SelArgs a{};
+    a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
+    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I;
+    const unsigned gy = (unsigned)((nq + TM - 1) / TM);
+    // bootstrap chunk through the slab
+    const size_t boot = f->nb < w.boot ? f->nb : w.boot;
+    t.nb_first = 0; t.nb_count = boot;
+    if (boot) hipLaunchKernelGGL(k_l2_tile<false>, dim3((unsigned)((boot + TN - 1) / TN), gy), dim3(256), 0, s, t);
+    a.nb_first = 0; a.nb_count = boot; a.mode = 0; a.first = 1; a.last = boot == f->nb;
+    hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+    // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a quarter of
+    // the candidate capacity
+    size_t pos = boot;
+    while (pos < f->nb) {
+        size_t chunk = pos * w.cap / (4 * (size_t)k);
+        chunk = chunk / TN * TN;
+        if (chunk < 4096) chunk = 4096;
+        if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
+        if (chunk > f->nb - pos) chunk = f->nb - pos;
+        t.nb_first = pos; t.nb_count = chunk;
+        hipLaunchKernelGGL(k_l2_tile<true>, dim3((unsigned)((chunk + TN - 1) / TN), gy), dim3(256), 0, s, t);
+        a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
+        hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+        pos += chunk;
     }
     PF_HIP(hipGetLastError());
     return PF_OK;

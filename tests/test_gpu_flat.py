@@ -58,6 +58,21 @@ def test_flat_search_gaussian_tolerance(pf):
         assert len(set(I[i])) == k
 
 
+def test_flat_search_adversarial_order_overflow_fallback(pf):
+    """Base rows ordered by DEcreasing distance to every query: each streamed row beats the running k-th distance,
+    the filtered candidate lists overflow, and the exact recomputation path has to produce the answer."""
+    nb, nq, k, d = 60000, 6, 200, 16
+    xb = np.zeros((nb, d), np.float32)
+    xb[:, 0] = np.arange(nb, 0, -1, dtype=np.float32) % 4096          # exact in fp32; plenty of ties as well
+    xb[:, 1] = (np.arange(nb) // 4096).astype(np.float32)[::-1]
+    xq = np.zeros((nq, d), np.float32)
+    xq[:, 2] = np.arange(nq)
+    idx = pf.FlatL2(xb, _dev())
+    D, I = idx.search(torch.from_numpy(xq).to(_dev()), k)
+    Dr, Ir = oracle.flat_l2_search(xb, xq, k)
+    assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
+
+
 def test_flat_search_odd_dimension(pf):
     rng = np.random.default_rng(6)
     xb, xq = _sift_like(rng, 3000, 30), _sift_like(rng, 9, 30)
