@@ -61,31 +61,41 @@ struct TileArgs {
     uint32_t *cand_cnt;     // [nq] survivors appended so far (may exceed cap: overflow marker)
     uint64_t *cand;         // [nq][cap] packed keys
     uint32_t cap;
+    uint32_t n_qtiles;
 };
 
-__device__ __forceinline__ void stage_slab(float *lds, const float *__restrict__ src, size_t row0, size_t rows_valid,
+// A 128-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
+// matrix pipe works on slab s: fetch (global -> registers: thread t holds row (t>>3)+32*it, k = (t&7)*4 .. +3)
+// and commit (registers -> LDS, transposed to lds[k][row]).
+__device__ __forceinline__ void slab_fetch(float4 (&v)[4], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
-    // 128 rows x 32 k: thread t loads row (t>>3)+32*it, k4 = (t&7)*4; stores transposed lds[k][row]
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = (tid >> 3) + 32 * it;
         const uint32_t k = k0 + (tid & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((size_t)row < rows_valid) {
             const float *p = src + (row0 + row) * (size_t)d + k;
-            if (((d & 3) == 0) && k + 3 < d) v = *reinterpret_cast<const float4 *>(p);
+            if (((d & 3) == 0) && k + 3 < d) v[it] = *reinterpret_cast<const float4 *>(p);
             else {
-                if (k < d) v.x = p[0];
-                if (k + 1 < d) v.y = p[1];
-                if (k + 2 < d) v.z = p[2];
-                if (k + 3 < d) v.w = p[3];
+                if (k < d) v[it].x = p[0];
+                if (k + 1 < d) v[it].y = p[1];
+                if (k + 2 < d) v[it].z = p[2];
+                if (k + 3 < d) v[it].w = p[3];
             }
         }
+    }
+}
+
+__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[4], int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = (tid >> 3) + 32 * it;
         const int kk = (tid & 7) * 4;
-        lds[(kk + 0) * LDA + row] = v.x;
-        lds[(kk + 1) * LDA + row] = v.y;
-        lds[(kk + 2) * LDA + row] = v.z;
-        lds[(kk + 3) * LDA + row] = v.w;
+        lds[(kk + 0) * LDA + row] = v[it].x;
+        lds[(kk + 1) * LDA + row] = v[it].y;
+        lds[(kk + 2) * LDA + row] = v[it].z;
+        lds[(kk + 3) * LDA + row] = v[it].w;
     }
 }
 
@@ -94,8 +104,14 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
     __shared__ float sA[TK * LDA];
     __shared__ float sB[TK * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t q0 = (size_t)blockIdx.y * TM;
-    const size_t c0 = (size_t)blockIdx.x * TN;                 // column inside the chunk
+    // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
+    // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the 64 KiB base tile is
+    // fetched from HBM once into that XCD's L2 and re-read from there by the other query tiles.
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint32_t qt = j % p.n_qtiles, ct = (j / p.n_qtiles) * 8 + xcd;
+    const size_t q0 = (size_t)qt * TM;
+    const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
+    if (c0 >= p.nb_count) return;
     const size_t q_valid = p.nq - q0 < TM ? p.nq - q0 : TM;
     const size_t c_valid = p.nb_count - c0 < TN ? p.nb_count - c0 : TN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -107,11 +123,18 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float4 ra[4], rb[4];
+    slab_fetch(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
     for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
+        __syncthreads();                               // the previous slab's fragment reads are done
+        slab_commit(sA, ra, tid);
+        slab_commit(sB, rb, tid);
         __syncthreads();
-        stage_slab(sA, p.xq, q0, q_valid, p.d, k0, tid);
-        stage_slab(sB, p.xb, p.nb_first + c0, c_valid, p.d, k0, tid);
-        __syncthreads();
+        if (k0 + TK < p.d) {                           // next slab's loads fly under this slab's MFMAs
+            slab_fetch(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
+            slab_fetch(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
+        }
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 2) {
             const int k = ks + (lane >> 5);
@@ -134,28 +157,38 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
         }
         __syncthreads();
     }
+    size_t col[2]; bool col_ok[2]; float bnv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const size_t col = c0 + wn + 32 * j + (lane & 31);
-        const bool col_ok = col < p.nb_count;
-        const float bnv = col_ok ? p.bn[p.nb_first + col] : 0.f;
+        col[j] = c0 + wn + 32 * j + (lane & 31);
+        col_ok[j] = col[j] < p.nb_count;
+        bnv[j] = col_ok[j] ? p.bn[p.nb_first + col[j]] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const size_t row = q0 + lrow;
-                if constexpr (FILTER) {
-                    float dist = fmaf(-2.f, acc[i][j][r], sA[lrow] + bnv);
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const size_t row = q0 + lrow;
+            if constexpr (FILTER) {
+                const float qnv = sA[lrow], tv = sA[TM + lrow];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float dist = fmaf(-2.f, acc[i][j][r], qnv + bnv[j]);
                     dist = dist < 0.f ? 0.f : dist;
-                    if (col_ok && dist <= sA[TM + lrow]) {           // ties pass; k_select orders by (distance, id)
+                    if (col_ok[j] && dist <= tv) {                   // ties pass; k_select orders by (distance, id)
                         const uint32_t pos = atomicAdd(&p.cand_cnt[row], 1u);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col));
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col[j]));
                     }
-                } else if (col_ok && row < p.nq) {
-                    float dist = fmaf(-2.f, acc[i][j][r], p.qn[row] + bnv);
+                }
+            } else if (row < p.nq) {
+                const float qnv = p.qn[row];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!col_ok[j]) continue;
+                    float dist = fmaf(-2.f, acc[i][j][r], qnv + bnv[j]);
                     dist = dist < 0.f ? 0.f : dist;
-                    p.slab[row * p.slab_ld + col] = dist;
+                    p.slab[row * p.slab_ld + col[j]] = dist;
                 }
             }
         }
@@ -434,7 +467,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     if (nq == 0) return PF_OK;
     if (!xq || !D || !I) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (k == 0 || k > SEL_CAP / 2) return fail(PF_ERR_UNSUPPORTED, "k must be in [1, 1024]");
-    if (nq > 0x7fffffffull / TM) return fail(PF_ERR_INVALID_ARG, "nq too large for one call");
+    if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
     hipStream_t s = as_stream(stream);
     const WsPlan w = plan_ws(f->nb, nq, k);
@@ -455,11 +488,12 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
     a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I;
-    const unsigned gy = (unsigned)((nq + TM - 1) / TM);
+    t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
+    auto tile_grid = [&](size_t cols) { const size_t nct = (cols + TN - 1) / TN; return dim3((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles)); };
     // bootstrap chunk through the slab
     const size_t boot = f->nb < w.boot ? f->nb : w.boot;
     t.nb_first = 0; t.nb_count = boot;
-    if (boot) hipLaunchKernelGGL(k_l2_tile<false>, dim3((unsigned)((boot + TN - 1) / TN), gy), dim3(256), 0, s, t);
+    if (boot) hipLaunchKernelGGL(k_l2_tile<false>, tile_grid(boot), dim3(256), 0, s, t);
     a.nb_first = 0; a.nb_count = boot; a.mode = 0; a.first = 1; a.last = boot == f->nb;
     hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
     // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a quarter of
@@ -472,7 +506,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
         if (chunk > f->nb - pos) chunk = f->nb - pos;
         t.nb_first = pos; t.nb_count = chunk;
-        hipLaunchKernelGGL(k_l2_tile<true>, dim3((unsigned)((chunk + TN - 1) / TN), gy), dim3(256), 0, s, t);
+        hipLaunchKernelGGL(k_l2_tile<true>, tile_grid(chunk), dim3(256), 0, s, t);
         a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
         hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
         pos += chunk;
