@@ -215,13 +215,13 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
 
 pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
 pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
 
@@ -236,8 +236,9 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
     if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
-    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, c->L, pt_count == 1 ? 1u : 0u};
-    return run_ntt_like(c, 2, flags, a, B * 2 * (size_t)c->L, stream);
+    const size_t pairs = B * (size_t)c->L;
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, pairs, c->L, pt_count == 1 ? 1u : 0u};
+    return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);     // grid: 8 XCD streams x 2 polynomials per pair
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@ struct NttArgs {
     const uint64_t *src;
     uint64_t *dst;
     const uint64_t *pt;
+    size_t n_pairs;          // ct x pt only: B * L (ciphertext, limb) pairs
     uint32_t L;
     uint32_t pt_broadcast;
 };
@@ -62,14 +63,21 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_nt
     else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
 }
 
-// Fused ct x pt: limb-polynomial blockIdx.x of the ciphertext batch [B][2][L][N].
+// Fused ct x pt over the ciphertext batch [B][2][L][N].  XCD-aware block order: blocks b and b+8 share an XCD
+// under round-robin placement, so XCD x takes the (ciphertext, limb) pairs m = x (mod 8) and runs the two
+// polynomials of a pair back to back -- the plaintext limb pt[b][l] they both multiply by is fetched from HBM
+// once and re-read from that XCD's L2 (rocprof FETCH_SIZE showed it coming from memory twice under the natural
+// order).  For L | 8 an XCD still only ever touches one or two limbs' twiddle tables.
 template <int LOGN, class A, int FLAGS>
 __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ctpt(NttArgs p) {
     using G = Geo<LOGN>;
     __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
-    const size_t poly = blockIdx.x;
-    const uint32_t limb = (uint32_t)(poly % p.L);
-    const size_t ctidx = poly / (2 * (size_t)p.L);
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const size_t m = (size_t)(j >> 1) * 8 + xcd;              // (ciphertext, limb) pair
+    if (m >= p.n_pairs) return;
+    const uint32_t limb = (uint32_t)(m % p.L);
+    const size_t ctidx = m / p.L;
+    const size_t poly = (ctidx * 2 + (j & 1)) * p.L + limb;   // limb-polynomial index in [B][2][L]
     const LimbDev &lm = p.limbs[limb];
     const A ar = ArithOf<A>::make(lm);
     const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
