@@ -40,7 +40,11 @@
 // sinking/hoisting their common LDS accesses into one block that picks the REGISTER by a pointer phi -- which
 // would demote the register-file array to scratch memory
 #define PF_BRANCH_TAG(s) asm volatile("; " s ::: "memory")
+// makes a value opaque to CSE: what is derived from it afterwards is recomputed instead of being kept alive
+// (and spilled) from its first use
+#define PF_LAUNDER(v) asm volatile("" : "+v"(v))
 #else
+#define PF_LAUNDER(v) ((void)0)
 #define PF_BRANCH_TAG(s) ((void)0)
 #define PF_HD inline
 #define PF_SCHED_FENCE() ((void)0)
@@ -699,6 +703,7 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
         store_last<G>(o, out, tid);
         return;
     }
+    if constexpr (!(FLAGS & CTPT_IN_NTT)) PF_LAUNDER(tid);   // the inverse half recomputes its LDS addresses: cheaper than keeping the forward half's alive
     inv_all<G, A>(r, ar, tl, itw, lds, tid, sync);
 #pragma unroll
     for (int k = 0; k < G::R; ++k) {
