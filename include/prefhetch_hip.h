@@ -60,7 +60,7 @@ pf_status pf_stream_synchronize(int device, pf_stream stream);
 /* ---- RNS ring context ------------------------------------------------------------------------- */
 /* Builds, per modulus: the minimal primitive 2N-th root psi, forward / inverse twiddle tables (with
  * Shoup quotients, and FP64 images when q < 2^45), Barrett ratio floor(2^128/q); uploads them.
- * Stands in for seal::SEALContext / util::NTTTables construction.  N in {1024,...,16384} (power of 2),
+ * Stands in for seal::SEALContext / util::NTTTables construction.  N in {1024,...,32768} (power of 2),
  * every modulus prime, < 2^61, = 1 mod 2N.  Blocking (synchronises the upload). */
 pf_status pf_ctx_create(pf_ctx **ctx, int device, uint32_t N, uint32_t L, const uint64_t *moduli_host);
 pf_status pf_ctx_destroy(pf_ctx *ctx);

@@ -30,6 +30,7 @@
 // index maps and the floating-point error analysis bit-for-bit on a machine without a GPU.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "lds_swizzle_tab.hpp"
 
 #if defined(__HIPCC__)
@@ -93,7 +94,8 @@ template <int LOGN_>
 struct Geo {
     static constexpr int LOGN = LOGN_;
     static constexpr int N = 1 << LOGN;
-    static constexpr int LOGR = LOGN >= 12 ? PF_LOGR_LARGE : 4;
+    // N = 32768: 64 coefficients per thread, 512 threads -- 2 waves per SIMD leave the 64-bit butterflies 256 VGPRs
+    static constexpr int LOGR = LOGN >= 15 ? 6 : (LOGN >= 12 ? PF_LOGR_LARGE : 4);
     static constexpr int R = 1 << LOGR;
     static constexpr int T = N / R;                               // threads per workgroup
     static constexpr int P = (LOGN + LOGR - 1) / LOGR;            // passes per transform
@@ -308,58 +310,102 @@ struct PassTw {
     static constexpr int NL = G::nl(PASS);
     static constexpr int off(int kb) { int o = 0; for (int j = 0; j < kb; ++j) o += G::R >> (j + 1); return o; }
     static constexpr int COUNT = off(NL);
+    // 16-byte (u64) twiddles are not held for a whole pass -- 63 of them would be 252 VGPRs -- but fetched where
+    // they are used; 8-byte FP64 twiddles are fetched up front (and, register budget permitting, before the exchange).
+    static constexpr bool LAZY = !A::PREFETCH_TW;
     // Pass 0's twiddles (table entries 1 .. R-1) are workgroup-uniform and arrive through the scalar cache; for the
     // FP64 back-end their quotients fl(w/q) are tabulated too (entries N .. N+R-1), so resolving them costs no VALU.
     static constexpr bool TABULATED_WQ = PASS == 0 && A::WQ0_TABLE;
-    typename A::Tw t[COUNT];
+    typename A::Tw t[LAZY ? 1 : COUNT];
     double wq[TABULATED_WQ ? COUNT : 1];
+    const typename A::Tw *tw_;
+    int tb_;
 
+    static constexpr int table_index(int kb, int g) {
+        return (1 << (G::LOGN - (G::a(PASS) + kb + 1))) + (G::koff(PASS, g << (kb + 1)) >> (G::a(PASS) + kb + 1));
+    }
+    PF_HD typename A::Tw fetch(int kb, int g) const {
+        if constexpr (PASS == 0) return const_load_tw(tw_ + table_index(kb, g));
+        else return (tw_ + table_index(kb, g))[tb_ >> (G::a(PASS) + kb + 1)];   // uniform pointer + per-lane index
+    }
     PF_HD void load(const typename A::Tw *__restrict__ tw, int tid) {
-        constexpr int aa = G::a(PASS);
-        const int tb = PASS == 0 ? 0 : G::base(PASS, tid);      // pass 0: every twiddle is workgroup-uniform
+        tw_ = tw;
+        tb_ = PASS == 0 ? 0 : G::base(PASS, tid);                // pass 0: every twiddle is workgroup-uniform
+        if constexpr (!LAZY) {
 #pragma unroll
-        for (int kb = 0; kb < NL; ++kb) {
-            const int sh = aa + kb + 1;
-            const int lane_idx = tb >> sh;                        // per-lane part; the rest of the address is workgroup-uniform
+            for (int kb = 0; kb < NL; ++kb) {
 #pragma unroll
-            for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
-                const int idx = (1 << (G::LOGN - sh)) + (G::koff(PASS, g << (kb + 1)) >> sh);
-                if constexpr (PASS == 0) t[off(kb) + g] = const_load_tw(tw + idx);
-                else t[off(kb) + g] = (tw + idx)[lane_idx];
-                if constexpr (TABULATED_WQ) wq[off(kb) + g] = const_load(reinterpret_cast<const double *>(tw) + G::N + idx);
+                for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
+                    t[off(kb) + g] = fetch(kb, g);
+                    if constexpr (TABULATED_WQ) wq[off(kb) + g] = const_load(reinterpret_cast<const double *>(tw) + G::N + table_index(kb, g));
+                }
             }
         }
     }
-    PF_HD typename A::TwR get(const A &ar, int i) const {
-        if constexpr (TABULATED_WQ) return A::with_quotient(t[i], wq[i]);
-        else return ar.resolve(t[i]);
+    PF_HD typename A::TwR get(const A &ar, int kb, int g) const {
+        if constexpr (LAZY) return ar.resolve(fetch(kb, g));
+        else if constexpr (TABULATED_WQ) return A::with_quotient(t[off(kb) + g], wq[off(kb) + g]);
+        else return ar.resolve(t[off(kb) + g]);
     }
 };
 
-template <class G, class A, int PASS>
-PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
+// One radix-2 stage (local bit KB) over the whole register file, NBATCH butterflies at a time.  Stages are
+// template instances, not iterations of a run-time loop: hipcc declines to fully unroll a 6-stage loop over 64
+// registers of 64-bit integer butterflies, and any surviving loop would index the register array dynamically.
+template <class G, class A, int PASS, int KB>
+PF_HD void fwd_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
     using V = typename A::V;
     using TwR = typename A::TwR;
 #pragma unroll
-    for (int kb = G::nl(PASS) - 1; kb >= 0; --kb) {
+    for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
+        V ys[NBATCH];
+        TwR ts[NBATCH];
+        PF_SCHED_FENCE();                 // keeps the twiddle resolves (w * 1/q) of later batches from piling up in registers
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            ys[i] = r[k0 | (1 << KB)];
+            ts[i] = T.get(ar, KB, b >> KB);
+        }
+        ar.template mul_tw_n<NBATCH>(ys, ts);
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            ar.fwd_combine(r[k0], r[k0 | (1 << KB)], ys[i]);
+        }
+    }
+    if constexpr (KB > 0) fwd_stage<G, A, PASS, KB - 1>(r, ar, T);
+}
+
+template <class G, class A, int PASS>
+PF_HD void fwd_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
+    fwd_stage<G, A, PASS, G::nl(PASS) - 1>(r, ar, T);
+}
+
+template <class G, class A, int PASS, int KB, int KB_HI>
+PF_HD void inv_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
+    using V = typename A::V;
+    using TwR = typename A::TwR;
+    if constexpr (KB <= KB_HI) {
 #pragma unroll
         for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
-            V ys[NBATCH];
+            V ds[NBATCH];
             TwR ts[NBATCH];
-            PF_SCHED_FENCE();                 // keeps the twiddle resolves (w * 1/q) of later batches from piling up in registers
+            PF_SCHED_FENCE();
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
-                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
-                ys[i] = r[k0 | (1 << kb)];
-                ts[i] = T.get(ar, PassTw<G, A, PASS>::off(kb) + (b >> kb));
+                const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+                ar.inv_split(r[k0], r[k0 | (1 << KB)], ds[i]);
+                ts[i] = T.get(ar, KB, b >> KB);
             }
-            ar.template mul_tw_n<NBATCH>(ys, ts);
+            ar.template mul_tw_n<NBATCH>(ds, ts);
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
-                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
-                ar.fwd_combine(r[k0], r[k0 | (1 << kb)], ys[i]);
+                const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+                r[k0 | (1 << KB)] = ds[i];
             }
         }
+        inv_stage<G, A, PASS, KB + 1, KB_HI>(r, ar, T);
     }
 }
 
@@ -368,27 +414,7 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
     using V = typename A::V;
     using TwR = typename A::TwR;
     constexpr int kb_hi = G::nl(PASS) - 1 - (PASS == 0 ? 1 : 0);   // pass 0 ends with the N^-1 layer below
-#pragma unroll
-    for (int kb = 0; kb <= kb_hi; ++kb) {
-#pragma unroll
-        for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
-            V ds[NBATCH];
-            TwR ts[NBATCH];
-            PF_SCHED_FENCE();
-#pragma unroll
-            for (int i = 0; i < NBATCH; ++i) {
-                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
-                ar.inv_split(r[k0], r[k0 | (1 << kb)], ds[i]);
-                ts[i] = T.get(ar, PassTw<G, A, PASS>::off(kb) + (b >> kb));
-            }
-            ar.template mul_tw_n<NBATCH>(ds, ts);
-#pragma unroll
-            for (int i = 0; i < NBATCH; ++i) {
-                const int b = bb + i, k0 = ((b >> kb) << (kb + 1)) | (b & ((1 << kb) - 1));
-                r[k0 | (1 << kb)] = ds[i];
-            }
-        }
-    }
+    inv_stage<G, A, PASS, 0, kb_hi>(r, ar, T);
     if constexpr (PASS == 0) {                               // last layer: fold N^-1 in (SEAL does the same)
         const TwR tn = A::WQ0_TABLE ? A::with_quotient(const_load_tw(itw), const_load(reinterpret_cast<const double *>(itw) + G::N)) : ar.resolve(const_load_tw(itw));
         const TwR t = A::WQ0_TABLE ? A::with_quotient(const_load_tw(itw + 1), const_load(reinterpret_cast<const double *>(itw) + G::N + 1)) : ar.resolve(const_load_tw(itw + 1));
@@ -410,6 +436,16 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
     }
 }
 
+// compile-time loop: f(integral_constant<int, I>) for I = BEGIN, BEGIN+STEP, ... < END (no run-time loop survives,
+// so register-array indices stay static whatever the unroller thinks of the body size)
+template <int I, int END, int STEP, class F>
+PF_HD void static_for(F &&f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + STEP, END, STEP>(f);
+    }
+}
+
 // element-wise helpers over the whole register file, in batches
 // Re-centre after inverse pass PASS.  Registers whose last transformed local bit is set came straight out of a
 // modular product (|v| < q) and are left alone; the other half accumulated sums.
@@ -417,34 +453,34 @@ template <class G, class A, int PASS>
 PF_HD void pass_reduce_all(typename A::V (&r)[G::R], const A &ar) {
     constexpr int TOP = 1 << (G::nl(PASS) - 1);
     constexpr int NB2 = 2 * NBATCH;
-#pragma unroll
-    for (int bb = 0; bb < G::R / 2; bb += NB2) {
+    static_for<0, G::R / 2, NB2>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
         typename A::V v[NB2];
 #pragma unroll
         for (int i = 0; i < NB2; ++i) { const int c = bb + i; v[i] = r[((c / TOP) * 2 * TOP) | (c % TOP)]; }
         ar.template pass_reduce_n<NB2>(v);
 #pragma unroll
         for (int i = 0; i < NB2; ++i) { const int c = bb + i; r[((c / TOP) * 2 * TOP) | (c % TOP)] = v[i]; }
-    }
+    });
 }
 
 template <class G, class A>
 PF_HD void canon_all(typename A::V (&r)[G::R], const A &ar) {
-#pragma unroll
-    for (int bb = 0; bb < G::R; bb += 2 * NBATCH) {
+    static_for<0, G::R, 2 * NBATCH>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
         typename A::V v[2 * NBATCH];
 #pragma unroll
         for (int i = 0; i < 2 * NBATCH; ++i) v[i] = r[bb + i];
         ar.template canon_n<2 * NBATCH>(v);
 #pragma unroll
         for (int i = 0; i < 2 * NBATCH; ++i) r[bb + i] = v[i];
-    }
+    });
 }
 
 template <class G, class A, bool LAZY_IN>
 PF_HD void dyadic_all(typename A::V (&r)[G::R], const typename A::V (&pv)[G::R], const A &ar) {
-#pragma unroll
-    for (int bb = 0; bb < G::R; bb += NBATCH) {
+    static_for<0, G::R, NBATCH>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
         typename A::V a[NBATCH], b[NBATCH];
 #pragma unroll
         for (int i = 0; i < NBATCH; ++i) { a[i] = r[bb + i]; b[i] = pv[bb + i]; }
@@ -452,7 +488,7 @@ PF_HD void dyadic_all(typename A::V (&r)[G::R], const typename A::V (&pv)[G::R],
         ar.template dyadic_n<NBATCH>(a, b);
 #pragma unroll
         for (int i = 0; i < NBATCH; ++i) r[bb + i] = a[i];
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,7 +508,10 @@ struct Xchg {
     // of its registers and reads the same half back, so N/2 LDS entries suffice and three workgroups instead of
     // two fit a CU's 160 KiB.  The thread's half is wave-uniform (T >= 128), so the register choice is a scalar
     // branch, not a per-lane select.
-    static constexpr bool HALF = PF_HALF_EXCHANGE && A::HALF_EXCHANGE_OK && G::P == 3 && G::nh(G::LAST) >= 1 && G::T >= 128;
+    // Forced when N*8 bytes do not fit a CU's LDS at all (N = 32768).
+    static constexpr bool FITS_WHOLE = G::N * 8 <= 128 * 1024;
+    static constexpr bool HALF = (!FITS_WHOLE || (PF_HALF_EXCHANGE && A::HALF_EXCHANGE_OK)) && G::P == 3 && G::nh(G::LAST) >= 1 && G::T >= 128;
+    static_assert(HALF || FITS_WHOLE, "this ring degree needs the half-buffer exchange");
     static constexpr int LDS_ENTRIES = HALF ? G::N / 2 : G::N;
 };
 

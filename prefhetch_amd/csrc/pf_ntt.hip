@@ -39,7 +39,8 @@ pf_status dispatch_logn(const pf_ctx *c, int arith, int op, int flags, const Ntt
         case 12: launch_logn_12(arith, op, flags, a, grid, s); break;
         case 13: launch_logn_13(arith, op, flags, a, grid, s); break;
         case 14: launch_logn_14(arith, op, flags, a, grid, s); break;
-        default: return fail(PF_ERR_UNSUPPORTED, "ring degree not built (supported: 1024..16384)");
+        case 15: launch_logn_15(arith, op, flags, a, grid, s); break;
+        default: return fail(PF_ERR_UNSUPPORTED, "ring degree not built (supported: 1024..32768)");
     }
     PF_HIP(hipGetLastError());
     return PF_OK;
@@ -142,7 +143,7 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
     *out = nullptr;
     uint32_t logn = 0;
     while ((1u << logn) < N) ++logn;
-    if ((1u << logn) != N || logn < 10 || logn > 14) return fail(PF_ERR_UNSUPPORTED, "N must be a power of two in [1024, 16384]");
+    if ((1u << logn) != N || logn < 10 || logn > 15) return fail(PF_ERR_UNSUPPORTED, "N must be a power of two in [1024, 32768]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PF_ERR_NO_DEVICE, "no such HIP device");
     PF_GUARD(device);

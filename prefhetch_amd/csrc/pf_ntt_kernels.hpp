@@ -135,6 +135,6 @@ namespace pf {
 // Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64;
 // op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`.
 #define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
-PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14)
+PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14) PF_DECL_LAUNCH(15)
 #undef PF_DECL_LAUNCH
 }  // namespace pf

@@ -45,8 +45,9 @@ struct LimbTables {
     std::vector<TwF64> fwd_f, inv_f;              // the same twiddles as doubles (8 bytes per entry), then 32 quotients
 };
 
-// Bound for ArithF64 (see ntt_core.hpp): 32*q <= 2^50 and (1+LOGN)*q <= 2^50.
-inline bool f64_path_ok(uint64_t q, int logn) { return q < (1ull << 45) && logn <= 15; }
+// Bound for ArithF64 (see ntt_core.hpp): R*q <= 2^50 (R = coefficients per thread: an inverse pass doubles R/2.. times
+// between re-centrings) and (1+LOGN)*q <= 2^50.
+inline bool f64_path_ok(uint64_t q, int logn) { return logn <= 15 && q < (1ull << (logn >= 15 ? 44 : 45)); }
 
 inline bool build_limb_tables(uint32_t N, uint64_t q, LimbTables &t, std::string &err) {
     int logn = 0;

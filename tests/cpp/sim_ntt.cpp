@@ -49,6 +49,7 @@ static void dispatch(int logn, int op, int flags, const A &ar, const typename A:
         case 12: run_op<12, A>(op, flags, ar, tw, itw, src, pt, dst); break;
         case 13: run_op<13, A>(op, flags, ar, tw, itw, src, pt, dst); break;
         case 14: run_op<14, A>(op, flags, ar, tw, itw, src, pt, dst); break;
+        case 15: run_op<15, A>(op, flags, ar, tw, itw, src, pt, dst); break;
     }
 }
 
@@ -57,7 +58,7 @@ extern "C" int pf_sim_run(int logn, uint64_t q, int arith, int op, int flags, co
                           const uint64_t *pt, uint64_t *dst) {
     LimbTables t;
     std::string err;
-    if (logn < 10 || logn > 14) return -1;
+    if (logn < 10 || logn > 15) return -1;
     if (!build_limb_tables(1u << logn, q, t, err)) return -2;
     if (arith == 0) {
         if (!t.f64_ok) return -3;

@@ -41,6 +41,7 @@ CONFIGS = [  # (N, moduli, force_u64)
     (8192, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001], False),   # 55-bit primes at N=8192 -> u64 path
     (16384, [0x7FFFFFFFE90001, 0x7FFFFFD8001], False),  # mixed widths -> u64 path
     (16384, [0x7FFFFFD8001, 0x7FFFFFC8001], False),      # exact-FP64 path at N=16384
+    (32768, oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:], False),   # config 5 ring: 55/56-bit primes, u64 path
 ]
 
 
@@ -179,12 +180,29 @@ def test_config3_full_size_properties(pf):
     assert torch.equal(acc, c.add(out, out))
 
 
+def test_config5_ring_ct_pt_slice(pf):
+    """BASELINE config 5 ring (N=32768, 15 data primes): ct x pt on an 8-ciphertext batch against the oracle."""
+    N, qs, B = 32768, oracle.BFV_DEFAULT[32768][:15], 8
+    rng = np.random.default_rng(20250801 + 5)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs], axis=2)
+    pt = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs], axis=1)
+    got = pf.to_host_u64(c.ct_pt_mul(pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev())))
+    assert (got == o.ct_pt_mul(ct, pt)).all()
+    d = pf.to_device_u64(ct, _dev())
+    c.ntt_forward_(d)
+    assert (pf.to_host_u64(d) == o.ntt_forward(ct)).all()
+    c.ntt_inverse_(d)
+    assert (pf.to_host_u64(d) == ct).all()
+
+
 def test_errors_are_statuses(pf):
     c = _ctx(pf, 1024, oracle.BFV_DEFAULT[1024])
     with pytest.raises(pf.PfError):
         pf.RnsContext(1024, [0x7E00003], _dev())          # not prime / not 1 mod 2N
     with pytest.raises(pf.PfError):
-        pf.RnsContext(32768, oracle.BFV_DEFAULT[32768][:1], _dev())   # degree not built yet
+        pf.RnsContext(65536, [0x7FFFFFFFE90001], _dev())              # degree not built
     empty = torch.empty((0, 1024), dtype=torch.int64, device=_dev())
     c.ntt_forward_(empty)                                  # empty batch is a no-op
     with pytest.raises(ValueError):

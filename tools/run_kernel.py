@@ -11,6 +11,11 @@ import prefhetch_amd as pf  # noqa: E402
 
 MODULI = [0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001]
 N = 8192
+if os.environ.get("PF_CONFIG") == "5":       # BASELINE config 5 ring: N=32768, 15 data primes (55-bit)
+    N = 32768
+    MODULI = [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0x7FFFFFFFBD0001, 0x7FFFFFFFBA0001, 0x7FFFFFFFAA0001, 0x7FFFFFFFA50001,
+              0x7FFFFFFF9F0001, 0x7FFFFFFF7E0001, 0x7FFFFFFF770001, 0x7FFFFFFF380001, 0x7FFFFFFF330001, 0x7FFFFFFF2D0001,
+              0x7FFFFFFF170001, 0x7FFFFFFF150001, 0x7FFFFFFEF00001]
 what = sys.argv[1] if len(sys.argv) > 1 else "ctpt"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
@@ -46,6 +51,6 @@ if what != "flat":
 torch.cuda.synchronize()
 if what != "flat":
     ms = e0.elapsed_time(e1) / reps
-    per = {"ctpt": 40, "ntt_fwd": 32, "ntt_inv": 32, "dyadic": 48}[what] * 4 * N * B
+    per = {"ctpt": 40, "ntt_fwd": 32, "ntt_inv": 32, "dyadic": 48}[what] * len(MODULI) * N * B
     print("%s: %.4f ms/launch  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (what, ms, per / ms / 1e6, per / ms / 1e6 / 80))
 print("done", what, reps, B)
