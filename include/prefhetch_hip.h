@@ -93,6 +93,18 @@ enum { PF_CTPT_ACCUMULATE = 1, PF_CTPT_IN_NTT = 2, PF_CTPT_OUT_NTT = 4 };
 pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, size_t pt_count,
                        uint64_t *out, size_t B, int flags, pf_stream stream);
 
+/* Evaluator::switch_key_inplace (what relinearize_inplace / rotate_rows / apply_galois run), BFV form: the
+ * polynomial `target` (coefficient form) is re-encrypted under the secret key through the key-switching key and
+ * ADDED into both components of `ct`.  `ctx` must hold the KEY moduli: the data primes q_0..q_{D-1} followed by
+ * the special prime P (SEAL's last coeff modulus); the ciphertexts live at the data level (D limbs).
+ *   target [B][D][N]        limb I canonical mod q_I
+ *   ksk    [D][2][D+1][N]   digit I's key as SEAL stores it (PublicKey data: 2 polys x K limbs), NTT form
+ *   ct     [B][2][D][N]     coefficient form, updated in place
+ * RNS digit decomposition -> D*(D+1) forward NTTs -> 128-bit lazy multiply-accumulate with the key ->
+ * inverse NTTs -> division by P with rounding.  Uses an internal workspace (16 ciphertexts per round) that is
+ * allocated on first use: call once outside graph capture. */
+pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
+
 /* ---- plaintext distance stages ---------------------------------------------------------------- */
 /* faiss::IndexFlatL2(d) + add(nb, xb): copies the base matrix [nb][d] fp32 (host or device pointer)
  * into HBM and precomputes row norms.  Blocking. */

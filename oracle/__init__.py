@@ -63,6 +63,7 @@ def lib():
         L.pfo_dyadic_mul.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int]
         L.pfo_poly_addsub.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int, C.c_int]
         L.pfo_ct_pt_mul.argtypes = [C.c_void_p, u64p, u64p, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int]
+        L.pfo_key_switch.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int]
         L.pfo_precise_search.argtypes = [f32p, f32p, i64p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
         L.pfo_gather_rows.argtypes = [f32p, i64p, C.c_size_t, C.c_size_t, f32p]
         L.pfo_flat_l2_search.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, f32p, i64p, C.c_int, C.c_int]
@@ -127,6 +128,17 @@ class Oracle:
         b = a if b is None else _u64(b)
         out = np.empty_like(a)
         lib().pfo_poly_addsub(self._h, _p(a, C.c_uint64), _p(b, C.c_uint64), _p(out, C.c_uint64), self._count(a), op, threads)
+        return out
+
+    def key_switch(self, target, ksk, ct, threads=0):
+        """Context moduli = key moduli (special prime last).  target [B,L,N], ksk [L,2,L+1,N] (NTT form),
+        ct [B,2,L,N] coefficient form; returns ct + switched polynomial."""
+        target, ksk = _u64(target), _u64(ksk)
+        out = _u64(ct).copy()
+        L = self.L - 1
+        B = target.size // (L * self.N)
+        assert ksk.size == L * 2 * self.L * self.N and out.size == B * 2 * L * self.N
+        lib().pfo_key_switch(self._h, _p(target, C.c_uint64), _p(ksk, C.c_uint64), _p(out, C.c_uint64), B, threads)
         return out
 
     def ct_pt_mul(self, ct, pt_ntt, flags=0, acc=None, threads=0):

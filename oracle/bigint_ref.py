@@ -120,3 +120,35 @@ def crt(residues, moduli):
         Mi = M // q
         x += r * Mi * pow(Mi, -1, q)
     return x % M, M
+
+
+def key_switch(target, ksk_ntt, ct, moduli, psis):
+    """Independent restatement of RNS key switching with one special prime (last modulus), everything in the
+    coefficient domain with big integers (no NTT-domain products): used to pin oracle A's pfo_key_switch.
+    target [L][N] coefficient form; ksk_ntt [L][2][K][N] NTT form; ct [2][L][N]; returns new ct."""
+    K = len(moduli)
+    L = K - 1
+    N = len(target[0])
+    P = moduli[-1]
+    half = P // 2
+    # keys to coefficient form, per modulus
+    key = [[[intt_direct(ksk_ntt[i][c][j], moduli[j], psis[j]) for j in range(K)] for c in range(2)] for i in range(L)]
+    out = [[list(ct[c][j]) for j in range(L)] for c in range(2)]
+    for c in range(2):
+        S = []
+        for j in range(K):
+            m = moduli[j]
+            acc = [0] * N
+            for i in range(L):
+                d = [x % m for x in target[i]]
+                prod = negacyclic_mul(d, key[i][c][j], m)
+                acc = [(a + p) % m for a, p in zip(acc, prod)]
+            S.append(acc)
+        t = [(x + half) % P for x in S[K - 1]]
+        for j in range(L):
+            q = moduli[j]
+            pinv = pow(P, -1, q)
+            for n in range(N):
+                r = (S[j][n] - t[n] + half) * pinv % q
+                out[c][j][n] = (out[c][j][n] + r) % q
+    return out

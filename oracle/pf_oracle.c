@@ -318,6 +318,66 @@ void pfo_ct_pt_mul(const pfo_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt,
     }
 }
 
+/* ------------------------------------------------------------------ key switching
+ * Evaluator::switch_key_inplace restated for the BFV case (target polynomial in coefficient form), SEAL
+ * evaluator.cpp [un-vendored; restated from the published algorithm, parity unpinned].  The context holds the KEY
+ * moduli q_0..q_{L-1}, P with the special prime P LAST; the ciphertext lives at the data level (first L moduli).
+ *   target [B][L][N]      coefficient form, limb I canonical mod q_I          (the polynomial being switched)
+ *   ksk    [L][2][K][N]   K = L+1; digit I's key (a PublicKey: 2 polys x K limbs) in NTT form
+ *   ct     [B][2][L][N]   coefficient form; the switched polynomial is ADDED into both components
+ * For every output modulus m_J (J < K) and component c:  S_J = sum_I NTT_{m_J}(target_I mod m_J) . ksk[I][c][J];
+ * then modulus switching with rounding:  t = (INTT_P(S_P) + floor(P/2)) mod P,
+ *   ct[c][J] += P^-1 * (INTT_J(S_J) - (t mod q_J) + (floor(P/2) mod q_J))   mod q_J.
+ * SEAL accumulates lazily in 128 bits and subtracts lazily; the residues it ends with are the canonical ones
+ * computed here. */
+void pfo_key_switch(const pfo_ctx *c, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, int nthreads) {
+    int nt = clamp_threads(nthreads); (void)nt;
+    const uint32_t N = c->N, K = c->L, L = K - 1;
+    const pfo_limb *mp = &c->limb[K - 1];
+    const uint64_t P = mp->q, half = P >> 1;
+    PAR_FOR
+    for (long b = 0; b < (long)B; b++) {
+        uint64_t *acc = (uint64_t *)malloc((size_t)2 * K * N * 8);     /* [2][K][N] products, NTT form then coefficient form */
+        uint64_t *tmp = (uint64_t *)malloc((size_t)N * 8);
+        for (uint32_t J = 0; J < K; J++) {
+            const pfo_limb *m = &c->limb[J];
+            uint64_t *a0 = acc + (size_t)J * N, *a1 = acc + ((size_t)K + J) * N;
+            memset(a0, 0, (size_t)N * 8); memset(a1, 0, (size_t)N * 8);
+            for (uint32_t I = 0; I < L; I++) {
+                const uint64_t *d = target + ((size_t)b * L + I) * N;
+                for (uint32_t n = 0; n < N; n++) tmp[n] = d[n] % m->q;
+                ntt_fwd_limb(m, N, tmp);
+                const uint64_t *k0 = ksk + (((size_t)I * 2 + 0) * K + J) * N, *k1 = ksk + (((size_t)I * 2 + 1) * K + J) * N;
+                for (uint32_t n = 0; n < N; n++) {
+                    uint64_t p0 = barrett_mul(tmp[n], k0[n], m), p1 = barrett_mul(tmp[n], k1[n], m);
+                    uint64_t s0 = a0[n] + p0, s1 = a1[n] + p1;
+                    a0[n] = s0 >= m->q ? s0 - m->q : s0;
+                    a1[n] = s1 >= m->q ? s1 - m->q : s1;
+                }
+            }
+            ntt_inv_limb(m, N, a0);
+            ntt_inv_limb(m, N, a1);
+        }
+        for (uint32_t comp = 0; comp < 2; comp++) {
+            uint64_t *tp = acc + ((size_t)comp * K + (K - 1)) * N;       /* special-prime component */
+            for (uint32_t n = 0; n < N; n++) { uint64_t t = tp[n] + half; tp[n] = t >= P ? t - P : t; }
+            for (uint32_t J = 0; J < L; J++) {
+                const pfo_limb *m = &c->limb[J];
+                const uint64_t q = m->q, halfj = half % q, pinv = invmod(P % q, q);
+                const uint64_t *sj = acc + ((size_t)comp * K + J) * N;
+                uint64_t *o = ct + (((size_t)b * 2 + comp) * L + J) * N;
+                for (uint32_t n = 0; n < N; n++) {
+                    uint64_t v = sj[n] + (q - tp[n] % q) + halfj;       /* < 3q */
+                    v %= q;
+                    uint64_t r = o[n] + mulmod_u128(v, pinv, q);
+                    o[n] = r >= q ? r - q : r;
+                }
+            }
+        }
+        free(acc); free(tmp);
+    }
+}
+
 /* ------------------------------------------------------------------ plaintext-distance rows */
 /* Server::preciseSearch, /root/reference/src/server/server_lib.cpp:151-164, literal semantics:
  * float dist; dist += std::pow(float_diff, 2)  ==  dist = (float)((double)dist + pow((double)diff, 2.0)). */

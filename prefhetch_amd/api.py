@@ -126,6 +126,20 @@ class RnsContext:
         return out
 
 
+    def key_switch_(self, target, ksk, ct):
+        """This context holds the key moduli (special prime last).  target [B,D,N], ksk [D,2,D+1,N] (NTT form),
+        ct [B,2,D,N]: the switched polynomial is added into ct in place."""
+        D = self.L - 1
+        if target.numel() % (D * self.N):
+            raise ValueError("target size is not a multiple of D*N")
+        B = target.numel() // (D * self.N)
+        if ksk.numel() != D * 2 * self.L * self.N or ct.numel() != B * 2 * D * self.N:
+            raise ValueError("ksk must be [D,2,D+1,N] and ct [B,2,D,N]")
+        pt, pk, pc = (_req(t, torch.int64, self.device_index, n) for t, n in ((target, "target"), (ksk, "ksk"), (ct, "ct")))
+        check(lib.pf_key_switch(self._h, pt, pk, pc, B, _stream(self.device)), "pf_key_switch")
+        return ct
+
+
 class FlatL2:
     def __init__(self, xb, device="cuda:0"):
         """xb: [nb, d] float32 numpy array or torch tensor (host or device); copied into HBM."""

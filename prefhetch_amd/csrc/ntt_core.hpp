@@ -263,8 +263,9 @@ struct ArithU64 {
     PF_HD void inv_split(V &x, V y, V &d) const { d = x + two_q - y; x = guard(x + y); }
     template <int NB> PF_HD void pass_reduce_n(V (&)[NB]) const {}
     // Barrett 128->64 (SEAL dyadic_product_coeffmod); operands must be canonical
-    PF_HD V dyadic(V a, V b) const {
-        const uint64_t z0 = a * b, z1 = mulhi64(a, b);
+    PF_HD V dyadic(V a, V b) const { return barrett128(a * b, mulhi64(a, b)); }
+    // (z1:z0) mod q for z < 2^128 / ... (SEAL barrett_reduce_128): result canonical
+    PF_HD V barrett128(uint64_t z0, uint64_t z1) const {
         const uint64_t carry = mulhi64(z0, ratio0);
         const uint64_t t2lo = z0 * ratio1, t2hi = mulhi64(z0, ratio1);
         uint64_t tmp1 = t2lo + carry;
@@ -649,6 +650,19 @@ PF_HD void load_l0(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
     for (int k = 0; k < G::R; ++k) r[k] = A::from_u64((src + G::koff(0, k))[tid]);
 }
 
+// same, reducing every coefficient modulo (q, ratio1 = high word of floor(2^128/q)) first: the RNS digit of key
+// switching is a residue of ANOTHER modulus (SEAL modulo_poly_coeffs / barrett_reduce_64)
+template <class G, class A>
+PF_HD void load_l0_mod(typename A::V (&r)[G::R], const uint64_t *src, int tid, uint64_t q, uint64_t ratio1) {
+#pragma unroll
+    for (int k = 0; k < G::R; ++k) {
+        const uint64_t x = (src + G::koff(0, k))[tid];
+        uint64_t v = x - mulhi64(x, ratio1) * q;
+        v = v >= q ? v - q : v;
+        r[k] = A::from_u64(v);
+    }
+}
+
 template <class G, class A>
 PF_HD void load_last(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
     constexpr int L = G::LAST, NL = G::nl(L);
@@ -689,6 +703,20 @@ PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, cons
                         uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0<G, A>(r, src, tid);
+    fwd_all<G, A>(r, ar, tw, lds, tid, sync);
+    canon_all<G, A>(r, ar);
+    uint64_t o[G::R];
+#pragma unroll
+    for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
+    store_last<G>(o, dst, tid);
+}
+
+// forward NTT of an RNS digit under another modulus: dst = NTT_q(src mod q)   (key switching, step 1)
+template <class G, class A, class Sync>
+PF_HD void body_ntt_fwd_mod(const A &ar, const typename A::Tw *__restrict__ tw, const uint64_t *src, uint64_t *dst,
+                            uint64_t q, uint64_t ratio1, typename A::V *lds, int tid, Sync &&sync) {
+    typename A::V r[G::R];
+    load_l0_mod<G, A>(r, src, tid, q, ratio1);
     fwd_all<G, A>(r, ar, tw, lds, tid, sync);
     canon_all<G, A>(r, ar);
     uint64_t o[G::R];

@@ -1,0 +1,101 @@
+// pf_ks_kernels.hpp -- element-wise kernels of key switching (steps 2 and 4 of SEAL's
+// Evaluator::switch_key_inplace; step 1, the digit NTTs, is k_ks_ntt in pf_ntt_kernels.hpp and step 3 the plain
+// inverse NTT).  The reference links SEAL un-vendored and never calls it (/root/reference/CMakeLists.txt:33-38);
+// BASELINE config 5 names the path.
+#pragma once
+#include "pf_ntt_kernels.hpp"
+
+namespace pf {
+
+struct KsArgs {
+    const LimbDev *limbs;
+    const uint64_t *x;       // [Bs][D][K][N] digit NTTs (step 1)
+    const uint64_t *ksk;     // [D][2][K][N]  key, NTT form
+    uint64_t *acc;           // [Bs][2][K][N] products: NTT form after step 2, coefficient form after the inverse NTT
+    uint64_t *ct;            // [Bs][2][D][N] ciphertext the switched polynomial is added into (step 4)
+    uint32_t D, K, logn;
+};
+
+// step 2: acc[b][c][J] = sum_I x[b][I][J] . ksk[I][c][J]  (mod m_J), accumulated in 128 bits like SEAL's lazy sum
+// (D <= 63 summands of < 2^122 each), reduced once.  One block per (b, J, 2048-coefficient chunk), 16 B per lane.
+__global__ void __launch_bounds__(256) k_ks_mac(KsArgs p) {
+    const uint32_t chunk_log = p.logn < 11 ? p.logn : 11;
+    const uint32_t chunks = 1u << (p.logn - chunk_log);
+    const uint32_t ch = blockIdx.x % chunks;
+    const size_t bj = blockIdx.x / chunks;
+    const uint32_t J = (uint32_t)(bj % p.K);
+    const size_t b = bj / p.K;
+    const LimbDev &lm = p.limbs[J];
+    const ArithU64 ar{lm.q, lm.two_q, lm.ratio0, lm.ratio1};
+    const size_t N = (size_t)1 << p.logn;
+    const uint32_t per_thread = (1u << chunk_log) / 512;
+    for (uint32_t jj = 0; jj < per_thread; ++jj) {
+        const size_t n2 = ((size_t)ch << chunk_log) / 2 + jj * 256 + threadIdx.x;      // index of a coefficient PAIR
+        uint64_t lo[2][2] = {{0, 0}, {0, 0}}, hi[2][2] = {{0, 0}, {0, 0}};            // [component][element]
+        for (uint32_t I = 0; I < p.D; ++I) {
+            const ulonglong2 xv = reinterpret_cast<const ulonglong2 *>(p.x + ((b * p.D + I) * p.K + J) * N)[n2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const ulonglong2 kv = reinterpret_cast<const ulonglong2 *>(p.ksk + (((size_t)I * 2 + c) * p.K + J) * N)[n2];
+                const uint64_t xs[2] = {xv.x, xv.y}, ks[2] = {kv.x, kv.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint64_t pl = xs[e] * ks[e], ph = mulhi64(xs[e], ks[e]);
+                    const uint64_t s = lo[c][e] + pl;
+                    hi[c][e] += ph + (s < pl ? 1 : 0);
+                    lo[c][e] = s;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ulonglong2 o;
+            const uint64_t r0 = ar.barrett128(lo[c][0], hi[c][0]), r1 = ar.barrett128(lo[c][1], hi[c][1]);
+            o.x = r0 >= lm.q ? r0 - lm.q : r0;
+            o.y = r1 >= lm.q ? r1 - lm.q : r1;
+            reinterpret_cast<ulonglong2 *>(p.acc + ((b * 2 + c) * p.K + J) * N)[n2] = o;
+        }
+    }
+}
+
+// step 4: modulus switching with rounding.  With s_J = acc[b][c][J] and s_P = acc[b][c][K-1] in coefficient form:
+//   t = (s_P + floor(P/2)) mod P;   ct[b][c][J] += P^-1 * (s_J - (t mod q_J) + (floor(P/2) mod q_J))   (mod q_J)
+__global__ void __launch_bounds__(256) k_ks_moddown(KsArgs p) {
+    const uint32_t chunk_log = p.logn < 11 ? p.logn : 11;
+    const uint32_t chunks = 1u << (p.logn - chunk_log);
+    const uint32_t ch = blockIdx.x % chunks;
+    const size_t bcj = blockIdx.x / chunks;
+    const uint32_t J = (uint32_t)(bcj % p.D);
+    const size_t bc = bcj / p.D;                          // b * 2 + component
+    const LimbDev &lm = p.limbs[J];
+    const LimbDev &lp = p.limbs[p.K - 1];
+    const uint64_t q = lm.q, P = lp.q, half = P >> 1;
+    const size_t N = (size_t)1 << p.logn;
+    const uint32_t per_thread = (1u << chunk_log) / 512;
+    const ulonglong2 *sj = reinterpret_cast<const ulonglong2 *>(p.acc + (bc * p.K + J) * N);
+    const ulonglong2 *sp = reinterpret_cast<const ulonglong2 *>(p.acc + (bc * p.K + (p.K - 1)) * N);
+    ulonglong2 *ct = reinterpret_cast<ulonglong2 *>(p.ct + (bc * p.D + J) * N);
+    auto one = [&](uint64_t s_j, uint64_t s_p, uint64_t c_in) {
+        uint64_t t = s_p + half;
+        t = t >= P ? t - P : t;
+        uint64_t tj = t - mulhi64(t, lm.ratio1) * q;                      // t mod q_J (barrett_reduce_64)
+        tj = tj >= q ? tj - q : tj;
+        uint64_t v = s_j + (q - tj) + lm.ks_half_mod;                      // < 3q
+        v = v >= 2 * q ? v - 2 * q : v;
+        v = v >= q ? v - q : v;
+        uint64_t r = v * lm.ks_pinv - mulhi64(v, lm.ks_pinv_quot) * q;     // Shoup product, [0, 2q)
+        r = r >= q ? r - q : r;
+        r += c_in;
+        return r >= q ? r - q : r;
+    };
+    for (uint32_t jj = 0; jj < per_thread; ++jj) {
+        const size_t n2 = ((size_t)ch << chunk_log) / 2 + jj * 256 + threadIdx.x;
+        const ulonglong2 a = sj[n2], b = sp[n2], c = ct[n2];
+        ulonglong2 o;
+        o.x = one(a.x, b.x, c.x);
+        o.y = one(a.y, b.y, c.y);
+        ct[n2] = o;
+    }
+}
+
+}  // namespace pf

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
+#include "pf_ks_kernels.hpp"
 #include "pf_ntt_kernels.hpp"
 #include "pf_common.hpp"
 #include "tables.hpp"
@@ -26,6 +27,8 @@ struct pf_ctx {
     std::vector<LimbTables> tabs;
     LimbDev *d_limbs = nullptr;
     void *d_tables = nullptr;       // all twiddle tables, one allocation
+    void *ks_ws = nullptr;          // key-switching workspace (digit NTTs + products), grown on demand
+    size_t ks_ws_bytes = 0;
 };
 
 namespace {
@@ -132,6 +135,7 @@ pf_status pf_ctx_destroy(pf_ctx *c) {
     {
         DeviceGuard g(c->device);
         if (c->d_tables) (void)hipFree(c->d_tables);
+        if (c->ks_ws) (void)hipFree(c->ks_ws);
         if (c->d_limbs) (void)hipFree(c->d_limbs);
     }
     delete c;
@@ -180,6 +184,14 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
         d.q = t.q; d.two_q = 2 * t.q; d.ratio0 = t.ratio0; d.ratio1 = t.ratio1;
         d.qd = (double)t.q; d.qinv = 1.0 / (double)t.q;
         d.fwd_u = append_u(t.fwd_u); d.inv_u = append_u(t.inv_u);
+        {   // key switching treats the LAST modulus as the special prime P
+            const uint64_t P = c->tabs[L - 1].q;
+            if (l + 1 < L) {
+                d.ks_half_mod = (P >> 1) % t.q;
+                d.ks_pinv = h_powmod(P % t.q, t.q - 2, t.q);
+                d.ks_pinv_quot = (uint64_t)((((u128_t)d.ks_pinv) << 64) / t.q);
+            }
+        }
         if (t.f64_ok) { d.fwd_f = append_f(t.fwd_f); d.inv_f = append_f(t.inv_f); }
     }
     if (hipMalloc(&c->d_tables, blob.size() * sizeof(uint64_t)) != hipSuccess ||
@@ -216,13 +228,13 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
 
 pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
 pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
     if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0};
+    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
 
@@ -238,8 +250,50 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
     if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
     const size_t pairs = B * (size_t)c->L;
-    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, pairs, c->L, pt_count == 1 ? 1u : 0u};
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, pairs, c->L, pt_count == 1 ? 1u : 0u, 0};
     return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);     // grid: 8 XCD streams x 2 polynomials per pair
+}
+
+pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (B == 0) return PF_OK;
+    if (!target || !ksk || !ct) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (c->L < 2) return fail(PF_ERR_INVALID_ARG, "key switching needs a context with the key moduli: data primes then the special prime");
+    const uint32_t K = c->L, D = K - 1;
+    if (D > 63) return fail(PF_ERR_UNSUPPORTED, "more than 63 digits would overflow the 128-bit lazy accumulator");
+    PF_GUARD(c->device);
+    hipStream_t s = as_stream(stream);
+    const size_t N = c->N;
+    const size_t sub = B < 16 ? B : 16;                                   // ciphertexts per round of the workspace
+    const size_t x_words = sub * D * K * N, acc_words = sub * 2 * K * N;
+    const size_t need = (x_words + acc_words) * 8;
+    if (need > c->ks_ws_bytes) {
+        if (c->ks_ws) { PF_HIP(hipFree(c->ks_ws)); c->ks_ws = nullptr; c->ks_ws_bytes = 0; }
+        PF_HIP(hipMalloc(&c->ks_ws, need));
+        c->ks_ws_bytes = need;
+    }
+    uint64_t *x = static_cast<uint64_t *>(c->ks_ws), *acc = x + x_words;
+    const int arith = (c->all_f64 && !c->force_u64) ? 0 : 1;
+    const uint32_t chunk_log = c->logn < 11 ? c->logn : 11;
+    const size_t chunks = N >> chunk_log;
+    for (size_t b0 = 0; b0 < B; b0 += sub) {
+        const size_t nb = B - b0 < sub ? B - b0 : sub;
+        // 1. digit NTTs: x[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)
+        NttArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, nullptr, 0, K, 0, D};
+        pf_status st = dispatch_logn(c, arith, 3, 0, a, nb * D * K, s);
+        if (st != PF_OK) return st;
+        // 2. multiply-accumulate with the key
+        KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn};
+        hipLaunchKernelGGL(k_ks_mac, dim3((unsigned)(nb * K * chunks)), dim3(256), 0, s, k);
+        // 3. back to coefficient form, all K limbs of both components
+        NttArgs ai{c->d_limbs, c->d_tables, acc, acc, nullptr, 0, K, 0, 0};
+        st = dispatch_logn(c, arith, 1, 0, ai, nb * 2 * K, s);
+        if (st != PF_OK) return st;
+        // 4. divide by the special prime with rounding and add into the ciphertext
+        hipLaunchKernelGGL(k_ks_moddown, dim3((unsigned)(nb * 2 * D * chunks)), dim3(256), 0, s, k);
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
 }
 
 }  // extern "C"

@@ -14,6 +14,9 @@ struct LimbDev {
     uint64_t q, two_q, ratio0, ratio1;
     double qd, qinv;
     uint32_t fwd_u, inv_u, fwd_f, inv_f;     // word offsets into NttArgs::tables (u64 tables 16-byte aligned)
+    // key switching with the LAST modulus of the context as special prime P
+    uint64_t ks_half_mod;                    // floor(P/2) mod q
+    uint64_t ks_pinv, ks_pinv_quot;          // P^-1 mod q and its Shoup quotient
 };
 
 struct NttArgs {
@@ -25,6 +28,7 @@ struct NttArgs {
     size_t n_pairs;          // ct x pt only: B * L (ciphertext, limb) pairs
     uint32_t L;
     uint32_t pt_broadcast;
+    uint32_t ks_decomp;      // key switching: number of digits (data limbs); L above is then the key-modulus count K
 };
 
 template <class A> struct ArithOf;
@@ -61,6 +65,22 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_nt
     uint64_t *dst = p.dst + poly * G::N;
     if constexpr (INVERSE) body_ntt_inv<G, A>(ar, ArithOf<A>::inv(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
     else body_ntt_fwd<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), src, dst, lds, (int)threadIdx.x, WgSync{});
+}
+
+// Key switching, step 1: block id = (b * D + I) * K + J computes X[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)
+// (D digits = data limbs, K = D+1 key moduli).  SEAL: modulo_poly_coeffs + ntt_negacyclic_harvey inside
+// Evaluator::switch_key_inplace.
+template <int LOGN, class A>
+__global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ks_ntt(NttArgs p) {
+    using G = Geo<LOGN>;
+    __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    const size_t id = blockIdx.x;
+    const uint32_t J = (uint32_t)(id % p.L);
+    const size_t digit = id / p.L;                       // b * D + I
+    const LimbDev &lm = p.limbs[J];
+    const A ar = ArithOf<A>::make(lm);
+    body_ntt_fwd_mod<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), p.src + digit * G::N, p.dst + id * G::N, lm.q, lm.ratio1, lds,
+                           (int)threadIdx.x, WgSync{});
 }
 
 // Fused ct x pt over the ciphertext batch [B][2][L][N].  XCD-aware block order: blocks b and b+8 share an XCD
@@ -133,7 +153,7 @@ __global__ void __launch_bounds__(256) k_elementwise(EwArgs p) {
 
 namespace pf {
 // Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64;
-// op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`.
+// op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`, 3 key-switch digit NTT.
 #define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
 PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14) PF_DECL_LAUNCH(15)
 #undef PF_DECL_LAUNCH

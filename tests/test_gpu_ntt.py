@@ -197,6 +197,51 @@ def test_config5_ring_ct_pt_slice(pf):
     assert (pf.to_host_u64(d) == ct).all()
 
 
+KS_CONFIGS = [  # (N, key moduli: data primes + special prime last, batch)
+    (1024, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0xFFFFFFFFF70001], 3),
+    (4096, oracle.BFV_DEFAULT[4096], 5),                        # 36/36-bit data + 37-bit special: exact-FP64 NTTs
+    (8192, oracle.BFV_DEFAULT[8192], 18),                       # 4 data + special, more than one workspace round
+    (32768, oracle.BFV_DEFAULT[32768][:3] + oracle.BFV_DEFAULT[32768][-1:], 2),
+]
+
+
+@pytest.mark.parametrize("N,qs,B", KS_CONFIGS)
+def test_key_switch_parity(pf, N, qs, B):
+    K, D = len(qs), len(qs) - 1
+    rng = np.random.default_rng(N + K)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    target = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs[:D]], axis=1)          # [B][D][N]
+    target[0, :, 0] = np.array(qs[:D], dtype=np.uint64) - 1
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+    ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs[:D]], axis=2)            # [B][2][D][N]
+    d_ct = pf.to_device_u64(ct, _dev())
+    c.key_switch_(pf.to_device_u64(target, _dev()), pf.to_device_u64(ksk, _dev()), d_ct)
+    assert (pf.to_host_u64(d_ct) == o.key_switch(target, ksk, ct)).all()
+
+
+def test_config5_key_switch_full_ring(pf):
+    """BASELINE config 5: N=32768, 15 data primes + special prime, key [15][2][16][32768] (126 MB): one ciphertext
+    against the oracle, and the same switch inside a batch of 20 (two workspace rounds) gives identical rows."""
+    N, qs = 32768, oracle.BFV_DEFAULT[32768]
+    K, D = 16, 15
+    rng = np.random.default_rng(20250801 + 5)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+    target = np.stack([rng.integers(0, q, (1, N), dtype=np.uint64) for q in qs[:D]], axis=1)
+    ct = np.stack([rng.integers(0, q, (1, 2, N), dtype=np.uint64) for q in qs[:D]], axis=2)
+    exp = o.key_switch(target, ksk, ct)
+    d_ksk = pf.to_device_u64(ksk, _dev())
+    d_ct = pf.to_device_u64(ct, _dev())
+    c.key_switch_(pf.to_device_u64(target, _dev()), d_ksk, d_ct)
+    assert (pf.to_host_u64(d_ct) == exp).all()
+    big_t = pf.to_device_u64(np.repeat(target, 20, axis=0), _dev())
+    big_c = pf.to_device_u64(np.repeat(ct, 20, axis=0), _dev())
+    c.key_switch_(big_t, d_ksk, big_c)
+    assert (pf.to_host_u64(big_c) == np.repeat(exp, 20, axis=0)).all()
+
+
 def test_errors_are_statuses(pf):
     c = _ctx(pf, 1024, oracle.BFV_DEFAULT[1024])
     with pytest.raises(pf.PfError):

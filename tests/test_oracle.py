@@ -141,3 +141,33 @@ def test_flat_l2_search_oracle():
     assert (I2 == I).all() and (D2 == D).all()
     D3, I3 = oracle.flat_l2_search(xb[:5], xq, 8)           # k > nb: (+inf, -1) padding
     assert (I3[:, 5:] == -1).all() and np.isinf(D3[:, 5:]).all()
+
+
+def test_key_switch_oracle_a_vs_bigint():
+    """pfo_key_switch (SEAL switch_key_inplace restated, NTT-domain products) against the coefficient-domain
+    big-integer restatement: RNS digits, one special prime, division by P with rounding."""
+    N, qs = 64, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0xFFFFFFFFF70001]       # 2 data primes + special, all = 1 mod 128
+    o = oracle.Oracle(N, qs)
+    psis = [o.psi(l) for l in range(3)]
+    rng = np.random.default_rng(3)
+    L, K = 2, 3
+    target = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    target[0, 0], target[1, 1] = qs[0] - 1, qs[1] - 1
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(L)])
+    ct = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]]) for _ in range(2)])
+    got = o.key_switch(target.reshape(1, L, N), ksk, ct.reshape(1, 2, L, N)).reshape(2, L, N)
+    as_int = lambda a: [int(x) for x in a]
+    ref = B.key_switch([as_int(r) for r in target], [[[as_int(ksk[i][c][j]) for j in range(K)] for c in range(2)] for i in range(L)],
+                       [[as_int(ct[c][j]) for j in range(L)] for c in range(2)], qs, psis)
+    assert (got == np.array(ref, dtype=np.uint64)).all()
+    # linearity in the target: switching t1 + t2 equals switching t1 then t2 up to the rounding of the division by P
+    t2 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    zero = np.zeros((1, 2, L, N), np.uint64)
+    a = o.key_switch(target.reshape(1, L, N), ksk, zero)
+    b = o.key_switch(t2.reshape(1, L, N), ksk, zero)
+    tsum = np.stack([(target[l].astype(object) + t2[l].astype(object)) % qs[l] for l in range(L)]).astype(np.uint64)
+    # digits of (t1+t2) differ from digit sums only by multiples of q_I, so compare through the exact big-int model
+    ref_sum = B.key_switch([as_int(r) for r in tsum], [[[as_int(ksk[i][c][j]) for j in range(K)] for c in range(2)] for i in range(L)],
+                           [[[0] * N for _ in range(L)] for _ in range(2)], qs, psis)
+    assert (o.key_switch(tsum.reshape(1, L, N), ksk, zero).reshape(2, L, N) == np.array(ref_sum, dtype=np.uint64)).all()
+    assert a.shape == b.shape
