@@ -21,6 +21,24 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
+if what == "keyswitch":          # PF_CONFIG=5: N=32768, 15 data primes + special; batch = argv[3]
+    assert os.environ.get("PF_CONFIG") == "5"
+    KQ = MODULI + [0xFFFFFFFFF70001]
+    D, K = len(MODULI), len(MODULI) + 1
+    ctx = pf.RnsContext(N, KQ, dev)
+    target = torch.stack([torch.randint(0, q, (B, N), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=1).contiguous()
+    ksk = torch.stack([torch.stack([torch.stack([torch.randint(0, q, (N,), generator=g, device=dev, dtype=torch.int64) for q in KQ]) for _ in range(2)]) for _ in range(D)]).contiguous()
+    ct = torch.stack([torch.randint(0, q, (B, 2, N), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=2).contiguous()
+    ctx.key_switch_(target, ksk, ct)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ctx.key_switch_(target, ksk, ct)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("keyswitch: %.3f ms per batch of %d (%.1f us per switched polynomial), %d digit NTTs of N=%d" % (ms, B, 1e3 * ms / B, B * D * K, N))
+    sys.exit(0)
 if what == "flat":
     xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
     xq = torch.randint(0, 256, (B, 128), generator=g, device=dev, dtype=torch.int32).float()
