@@ -122,6 +122,25 @@ pf_status pf_l2_gathered(pf_flat *idx, const float *xq, const int64_t *ids, size
  * out[i] = base row ids[i].  ids [n_ids] int64, out [n_ids][d]. */
 pf_status pf_gather_rows(pf_flat *idx, const int64_t *ids, size_t n_ids, float *out, pf_stream stream);
 
+/* ---- IVF-PQ coarse stage (Server::coarseSearch, /root/reference/src/server/server_lib.cpp:111-138) ------------- */
+/* faiss::IndexIVFPQ(quantizer, d, nlist, M, 8) with trained tables: coarse centroids [nlist][d] and PQ codebooks
+ * [M][256][d/M] (host pointers, copied).  by_residual semantics: codes quantise x - centroid. */
+typedef struct pf_ivfpq pf_ivfpq;
+pf_status pf_ivfpq_create(pf_ivfpq **idx, int device, uint32_t d, uint32_t nlist, uint32_t M, const float *centroids_host,
+                          const float *codebooks_host);
+pf_status pf_ivfpq_destroy(pf_ivfpq *idx);
+/* IndexIVFPQ::add after assignment/encoding: vector i goes to list list_ids_host[i] with code codes_host[i][M], label ids_host[i]. */
+pf_status pf_ivfpq_add_encoded(pf_ivfpq *idx, size_t n, const int64_t *list_ids_host, const uint8_t *codes_host, const int64_t *ids_host);
+pf_status pf_ivfpq_info(const pf_ivfpq *idx, uint32_t *d, uint32_t *nlist, uint32_t *M, size_t *ntotal, uint64_t *list_sizes_host);
+pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_host, int64_t *ids_host);
+/* IndexIVFPQ::search_encrypted (PreFHEtch-faiss fork; semantics from the call site and its consumer,
+ * src/client/client_lib.cpp:122-156): for query q and each of its nprobe GIVEN lists, in the given order, the asymmetric
+ * PQ distance and label of EVERY stored vector, unsorted; a query's results are contiguous, queries back to back;
+ * list_sizes_host[q] = number of results of query q.  xq [nq][d] device, probe_host [nq][nprobe] host (-1 = skip),
+ * D / I device buffers of `capacity` entries.  Synchronises `stream` once (staging of the probe ids). */
+pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
+                                int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
+
 /* Bytes of scratch pf_flat_search needs for (nq, k); the library grows an internal workspace on
  * first use (outside graph capture) -- call pf_flat_reserve up front to keep searches allocation-free. */
 pf_status pf_flat_reserve(pf_flat *idx, size_t nq_max, uint32_t k_max);

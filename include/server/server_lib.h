@@ -34,9 +34,10 @@ class Server {
         return server;
     }
 
-    // Loads ../sift/siftsmall/siftsmall_base.fvecs into HBM and the IVF centroids from the cache file next to it
-    // (reference src/server/server_lib.cpp:55-99).  Training the IVFPQ index is not part of this build: when no
-    // centroid cache exists this throws std::runtime_error, as the reference does for an unusable index file.
+    // Reference src/server/server_lib.cpp:55-99: when no cached index file exists, trains the IVF-PQ index
+    // (NLIST=256 coarse centroids, 32 x 8-bit sub-quantizers) on ../sift/siftsmall/siftsmall_learn.fvecs, adds
+    // ../sift/siftsmall/siftsmall_base.fvecs and writes the cache; otherwise loads base + cache.  The cache is this
+    // build's own format (the reference's is faiss::write_index).  k-means assignments run on the GPU flat index.
     void init_index();
     // Serves the four routes through Drogon when built with -DPREFHETCH_WITH_DROGON; otherwise throws.
     void run_webserver();
@@ -53,8 +54,12 @@ class Server {
                           std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY> &query_results);
 
     // ---- additions of this build (not in the reference) ---------------------------------------------------
-    // Installs base vectors [nb][128] and centroids [nlist][128] from host memory instead of the dataset files.
-    void init_from_memory(const float *base, size_t nb, const float *centroids, size_t nlist, int device = 0);
+    // Dataset-free init: trains on `train` [nt][128] (on the base vectors when train == nullptr) and adds base [nb][128].
+    void init_from_memory(const float *base, size_t nb, const float *train = nullptr, size_t nt = 0, int device = 0);
+    // Trained index content in flat form (test / serialisation hook): centroids [NLIST][128], codebooks [32][256][4],
+    // list-contiguous codes [ntotal][32] and ids [ntotal], list offsets [NLIST+1].
+    void export_index(std::vector<float> &centroids, std::vector<float> &codebooks, std::vector<uint8_t> &codes,
+                      std::vector<faiss::idx_t> &ids, std::vector<uint64_t> &list_offsets) const;
     // The executed flat-L2 shortlist of the protocol (client sort_nearest_centroids, src/client/client_lib.cpp:50-81)
     // on the server's IndexFlatL2 over the centroids: top-NPROBE centroid ids (and squared distances) per query.
     void nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,

@@ -63,6 +63,9 @@ def lib():
         L.pfo_dyadic_mul.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int]
         L.pfo_poly_addsub.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int, C.c_int]
         L.pfo_ct_pt_mul.argtypes = [C.c_void_p, u64p, u64p, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int]
+        L.pfo_ivfpq_search_lists.restype = C.c_size_t
+        L.pfo_ivfpq_search_lists.argtypes = [f32p, C.c_size_t, i64p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p,
+                                             C.POINTER(C.c_uint8), i64p, u64p, f32p, i64p, u64p]
         L.pfo_key_switch.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_int]
         L.pfo_precise_search.argtypes = [f32p, f32p, i64p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
         L.pfo_gather_rows.argtypes = [f32p, i64p, C.c_size_t, C.c_size_t, f32p]
@@ -180,6 +183,28 @@ def flat_l2_search(xb, xq, k, mode=0, threads=0, f32=False):
     else:
         lib().pfo_flat_l2_search(_p(xb, C.c_float), xb.shape[0], xb.shape[1], _p(xq, C.c_float), nq, k, _p(D, C.c_float), _p(I, C.c_int64), mode, threads)
     return D, I
+
+
+def ivfpq_search_lists(xq, probe, centroids, codebooks, codes, ids, list_off):
+    """ADC scan of the given lists (IndexIVFPQ::search_encrypted restated).  Returns (D, I, list_sizes)."""
+    xq = np.ascontiguousarray(xq, np.float32)
+    probe = np.ascontiguousarray(probe, np.int64)
+    centroids = np.ascontiguousarray(centroids, np.float32)
+    codebooks = np.ascontiguousarray(codebooks, np.float32)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    ids = np.ascontiguousarray(ids, np.int64)
+    list_off = np.ascontiguousarray(list_off, np.uint64)
+    nq, nprobe = probe.shape
+    nlist, d = centroids.shape
+    M = codebooks.shape[0]
+    cap = int(sum(int(list_off[l + 1] - list_off[l]) for l in probe.ravel() if 0 <= l < nlist))
+    D = np.empty(max(cap, 1), np.float32)
+    I = np.empty(max(cap, 1), np.int64)
+    sizes = np.zeros(nq, np.uint64)
+    n = lib().pfo_ivfpq_search_lists(_p(xq, C.c_float), nq, _p(probe, C.c_int64), nprobe, _p(centroids, C.c_float), nlist, d, M,
+                                     _p(codebooks, C.c_float), _p(codes, C.c_uint8), _p(ids, C.c_int64), _p(list_off, C.c_uint64),
+                                     _p(D, C.c_float), _p(I, C.c_int64), _p(sizes, C.c_uint64))
+    return D[:n], I[:n], sizes
 
 
 def max_threads():

@@ -396,6 +396,44 @@ void pfo_gather_rows(const float *base, const int64_t *ids, size_t n_ids, size_t
     for (size_t i = 0; i < n_ids; i++) memcpy(out + i * d, base + (size_t)ids[i] * d, d * sizeof(float));
 }
 
+/* IndexIVFPQ::search_encrypted restated (fork source absent; semantics from server_lib.cpp:126-135 and its consumer
+ * client_lib.cpp:122-156, arithmetic contract in prefhetch_amd/csrc/pf_ivfpq.hip): every vector of every GIVEN list, in
+ * order; residual tables in fp32, mul then add, no contraction; distance = in-order fp32 sum over sub-quantizers.
+ * Index content is passed in flat form: codes/ids list-contiguous with list_off[nlist+1]. Returns the total count. */
+size_t pfo_ivfpq_search_lists(const float *xq, size_t nq, const int64_t *probe, size_t nprobe, const float *centroids, size_t nlist,
+                              size_t d, size_t M, const float *codebooks, const uint8_t *codes, const int64_t *ids,
+                              const uint64_t *list_off, float *D, int64_t *I, uint64_t *list_sizes) {
+    const size_t dsub = d / M;
+    size_t out = 0;
+    float *lut = (float *)malloc(M * 256 * sizeof(float));
+    for (size_t q = 0; q < nq; q++) {
+        uint64_t per_q = 0;
+        for (size_t j = 0; j < nprobe; j++) {
+            const int64_t l = probe[q * nprobe + j];
+            if (l < 0 || (size_t)l >= nlist) continue;
+            for (size_t m = 0; m < M; m++)
+                for (size_t c = 0; c < 256; c++) {
+                    float acc = 0.f;
+                    for (size_t t = 0; t < dsub; t++) {
+                        volatile float r = xq[q * d + m * dsub + t] - centroids[(size_t)l * d + m * dsub + t];
+                        volatile float diff = r - codebooks[(m * 256 + c) * dsub + t];
+                        volatile float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+                    lut[m * 256 + c] = acc;
+                }
+            for (uint64_t v = list_off[l]; v < list_off[l + 1]; v++) {
+                float dis = 0.f;
+                for (size_t m = 0; m < M; m++) dis = dis + lut[m * 256 + codes[v * M + m]];
+                D[out] = dis; I[out] = ids[v]; out++; per_q++;
+            }
+        }
+        list_sizes[q] = per_q;
+    }
+    free(lut);
+    return out;
+}
+
 typedef struct { float dis; int64_t id; } pfo_hit;
 static int hit_cmp(const void *a, const void *b) {
     const pfo_hit *x = (const pfo_hit *)a, *y = (const pfo_hit *)b;

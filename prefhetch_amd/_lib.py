@@ -18,6 +18,7 @@ SYMBOLS = [
     "pf_ct_pt_mul", "pf_key_switch",
     "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
     "pf_flat_reserve",
+    "pf_ivfpq_create", "pf_ivfpq_destroy", "pf_ivfpq_add_encoded", "pf_ivfpq_info", "pf_ivfpq_get_list", "pf_ivfpq_search_lists",
 ]
 
 
@@ -62,6 +63,12 @@ def _load():
     lib.pf_l2_gathered.argtypes = [vp, vp, vp, sz, u32, vp, vp]
     lib.pf_gather_rows.argtypes = [vp, vp, sz, vp, vp]
     lib.pf_flat_reserve.argtypes = [vp, sz, u32]
+    lib.pf_ivfpq_create.argtypes = [C.POINTER(vp), i32, u32, u32, u32, vp, vp]
+    lib.pf_ivfpq_destroy.argtypes = [vp]
+    lib.pf_ivfpq_add_encoded.argtypes = [vp, sz, vp, vp, vp]
+    lib.pf_ivfpq_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(sz), vp]
+    lib.pf_ivfpq_get_list.argtypes = [vp, u32, vp, vp]
+    lib.pf_ivfpq_search_lists.argtypes = [vp, vp, vp, sz, u32, vp, vp, sz, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         if name not in ("pf_status_str", "pf_last_error"):

@@ -190,3 +190,58 @@ class FlatL2:
         out = torch.empty(tuple(ids.shape) + (self.d,), dtype=torch.float32, device=self.device)
         check(lib.pf_gather_rows(self._h, pi, ids.numel(), C.c_void_p(out.data_ptr()), _stream(self.device)), "pf_gather_rows")
         return out
+
+
+class IvfPq:
+    """faiss::IndexIVFPQ (8-bit sub-quantizers, by_residual) with trained tables: the index behind Server::coarseSearch
+    (reference src/server/server_lib.cpp:33-36,111-138)."""
+
+    def __init__(self, centroids, codebooks, device="cuda:0"):
+        self.device_index = _dev_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        centroids = np.ascontiguousarray(centroids, np.float32)
+        codebooks = np.ascontiguousarray(codebooks, np.float32)
+        self.nlist, self.d = centroids.shape
+        self.M = codebooks.shape[0]
+        if codebooks.shape != (self.M, 256, self.d // self.M):
+            raise ValueError("codebooks must be [M, 256, d/M]")
+        h = C.c_void_p()
+        check(lib.pf_ivfpq_create(C.byref(h), self.device_index, self.d, self.nlist, self.M, centroids.ctypes.data_as(C.c_void_p),
+                                  codebooks.ctypes.data_as(C.c_void_p)), "pf_ivfpq_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pf_ivfpq_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def add_encoded(self, list_ids, codes, ids):
+        list_ids = np.ascontiguousarray(list_ids, np.int64)
+        codes = np.ascontiguousarray(codes, np.uint8)
+        ids = np.ascontiguousarray(ids, np.int64)
+        if codes.shape != (list_ids.size, self.M) or ids.size != list_ids.size:
+            raise ValueError("codes must be [n, M]; ids and list_ids [n]")
+        check(lib.pf_ivfpq_add_encoded(self._h, list_ids.size, list_ids.ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p),
+                                       ids.ctypes.data_as(C.c_void_p)), "pf_ivfpq_add_encoded")
+
+    def list_sizes(self):
+        sizes = np.zeros(self.nlist, np.uint64)
+        check(lib.pf_ivfpq_info(self._h, None, None, None, None, sizes.ctypes.data_as(C.c_void_p)), "pf_ivfpq_info")
+        return sizes
+
+    def search_lists(self, xq, probe):
+        """xq [nq,d] float32 on the device, probe [nq,nprobe] int64 numpy (host).  Returns (D, I, list_sizes)."""
+        pq = _req(xq, torch.float32, self.device_index, "xq")
+        probe = np.ascontiguousarray(probe, np.int64)
+        nq, nprobe = probe.shape
+        sizes = self.list_sizes()
+        cap = int(sum(int(sizes[l]) for l in probe.ravel() if 0 <= l < self.nlist))
+        D = torch.empty(max(cap, 1), dtype=torch.float32, device=self.device)
+        I = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
+        per_q = np.zeros(nq, np.uint64)
+        check(lib.pf_ivfpq_search_lists(self._h, pq, probe.ctypes.data_as(C.c_void_p), nq, nprobe, C.c_void_p(D.data_ptr()),
+                                        C.c_void_p(I.data_ptr()), cap, per_q.ctypes.data_as(C.c_void_p), _stream(self.device)),
+              "pf_ivfpq_search_lists")
+        return D[:cap], I[:cap], per_q

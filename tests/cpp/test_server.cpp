@@ -40,15 +40,36 @@ int main(int argc, char **argv) {
     std::uniform_int_distribution<int> pix(0, 255);
     std::normal_distribution<float> gauss(0.f, 1.f);
     auto draw = [&] { return gaussian ? gauss(rng) : static_cast<float>(pix(rng)); };
-    std::vector<float> base(static_cast<size_t>(NBASE) * 128), cent(static_cast<size_t>(NLIST) * 128);
+    const size_t NT = 6000;                                    // training vectors (the reference trains on siftsmall_learn)
+    std::vector<float> base(static_cast<size_t>(NBASE) * 128), train(NT * 128);
     for (float &v : base) v = draw();
-    for (float &v : cent) v = draw();
+    for (float &v : train) v = draw();
     auto &srv = Server::getInstance();
     EXPECT(srv.get() == Server::getInstance().get());
     bool threw = false;
     try { std::vector<std::array<float, 128>> c; srv->retrieve_centroids(c); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);                                   // not initialised yet -> runtime_error, like an unusable index in the reference
-    srv->init_from_memory(base.data(), NBASE, cent.data(), NLIST);
+    srv->init_from_memory(base.data(), NBASE, train.data(), NT);
+    std::vector<float> cent, books; std::vector<uint8_t> codes; std::vector<faiss::idx_t> stored_ids; std::vector<uint64_t> off;
+    srv->export_index(cent, books, codes, stored_ids, off);
+    EXPECT(cent.size() == static_cast<size_t>(NLIST) * 128 && books.size() == 32u * 256 * 4 && stored_ids.size() == static_cast<size_t>(NBASE));
+    {   // every base row is stored exactly once, in the list of its nearest centroid (ties -> smaller id), fp64 check with slack
+        std::vector<int> seen(NBASE, 0);
+        for (size_t l = 0; l < static_cast<size_t>(NLIST); ++l)
+            for (uint64_t v = off[l]; v < off[l + 1]; ++v) {
+                const int64_t id = stored_ids[v];
+                ++seen[id];
+                double dl = 0, best = 1e300;
+                for (size_t c = 0; c < static_cast<size_t>(NLIST); ++c) {
+                    double dd = 0;
+                    for (int t = 0; t < 128; ++t) { const double df = double(base[id * 128 + t]) - double(cent[c * 128 + t]); dd += df * df; }
+                    if (c == l) dl = dd;
+                    best = std::min(best, dd);
+                }
+                EXPECT(dl <= best * (1 + 1e-5));
+            }
+        EXPECT(std::all_of(seen.begin(), seen.end(), [](int c) { return c == 1; }));
+    }
 
     Q query;
     for (auto &q : query) for (float &v : q) v = draw();
@@ -95,23 +116,53 @@ int main(int argc, char **argv) {
         }
         std::sort(all.begin(), all.end());
         for (int j = 0; j < NPROBE; j++) {
-            if (gaussian) {          // fp32 distances within 1e-5 relative (north_star); ids may swap only inside that band
-                EXPECT(std::fabs(cdist[i][j] - all[j].first) <= 1e-5f * all[j].first);
-            } else {
-                EXPECT(cid[i][j] == all[j].second);
-                EXPECT(cdist[i][j] == all[j].first);
+            // trained centroids are real-valued, so fp32 distances are held to the north-star tolerance (1e-5 relative);
+            // an id may only differ from the reference order inside that band
+            EXPECT(std::fabs(cdist[i][j] - all[j].first) <= 1e-5f * all[j].first);
+            if (cid[i][j] != all[j].second) {
+                float dref = -1.f;
+                for (auto &pr : all) if (pr.second == cid[i][j]) dref = pr.first;
+                EXPECT(std::fabs(dref - all[j].first) <= 2e-5f * all[j].first);
             }
         }
     }
 
-    // coarseSearch is a "next" row: must fail loudly, not return garbage
-    threw = false;
-    try {
-        std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> nc{};
+    // coarseSearch: literal restatement of the ADC scan over the client-chosen lists (server_lib.cpp:111-138; arithmetic
+    // contract of pf_ivfpq.hip) on the exported index content, bit-exact
+    {
+        std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> probe = cid;       // the lists a client would pick
         std::vector<float> s; std::vector<faiss::idx_t> l; std::array<size_t, NQUERY> sz{};
-        srv->coarseSearch(query, nc, s, l, sz);
-    } catch (const std::runtime_error &) { threw = true; }
-    EXPECT(threw);
+        srv->coarseSearch(query, probe, s, l, sz);
+        std::vector<float> rs; std::vector<faiss::idx_t> rl; std::array<size_t, NQUERY> rsz{};
+        std::vector<float> lut(32 * 256);
+        for (int i = 0; i < NQUERY; i++) {
+            for (int j = 0; j < NPROBE; j++) {
+                const int64_t li = probe[i][j];
+                for (int m = 0; m < 32; m++)
+                    for (int c = 0; c < 256; c++) {
+                        float acc = 0.f;
+                        for (int t = 0; t < 4; t++) {
+                            volatile float r = query[i][m * 4 + t] - cent[li * 128 + m * 4 + t];
+                            volatile float diff = r - books[(m * 256 + c) * 4 + t];
+                            volatile float sq = diff * diff;
+                            acc = acc + sq;
+                        }
+                        lut[m * 256 + c] = acc;
+                    }
+                for (uint64_t v = off[li]; v < off[li + 1]; ++v) {
+                    float dis = 0.f;
+                    for (int m = 0; m < 32; m++) dis = dis + lut[m * 256 + codes[v * 32 + m]];
+                    rs.push_back(dis); rl.push_back(stored_ids[v]); ++rsz[i];
+                }
+            }
+        }
+        EXPECT(sz == rsz);
+        EXPECT(l == rl);
+        EXPECT(s.size() == rs.size() && std::memcmp(s.data(), rs.data(), rs.size() * 4) == 0);
+        size_t total = 0;
+        for (size_t v : sz) total += v;
+        EXPECT(total == s.size() && total > 0);
+    }
 
     Timer t; long long us = -1, ms = -1;
     t.StartTimer(); t.StopTimer(); t.getDuration(us, ms);

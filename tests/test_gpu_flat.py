@@ -131,3 +131,31 @@ def test_config3_prefilter_full_size(pf):
     assert all(len(set(r)) == k for r in I[:64].cpu().numpy())
     Dr, Ir = oracle.flat_l2_search(xb, xq[500:516], k)
     assert (I[500:516].cpu().numpy() == Ir).all() and (D[500:516].cpu().numpy() == Dr).all()
+
+
+@pytest.mark.parametrize("d,M,nlist,n,nq,nprobe", [(128, 32, 256, 10000, 5, 20), (64, 8, 16, 3000, 9, 3), (24, 6, 7, 500, 4, 7)])
+def test_ivfpq_search_lists_bit_exact(pf, d, M, nlist, n, nq, nprobe):
+    """IndexIVFPQ::search_encrypted semantics (Server::coarseSearch, server_lib.cpp:111-138): ADC over the GIVEN lists,
+    all stored vectors, unsorted, bit-exact against the oracle on the same index content (reference shapes first)."""
+    rng = np.random.default_rng(d + M + n)
+    cent = rng.standard_normal((nlist, d)).astype(np.float32) * 30
+    books = rng.standard_normal((M, 256, d // M)).astype(np.float32) * 5
+    lists = rng.integers(0, nlist, n).astype(np.int64)
+    lists[lists == 1] = 0                                           # list 1 stays empty
+    codes = rng.integers(0, 256, (n, M)).astype(np.uint8)
+    ids = rng.permutation(n).astype(np.int64)
+    idx = pf.IvfPq(cent, books, _dev())
+    idx.add_encoded(lists[: n // 2], codes[: n // 2], ids[: n // 2])           # two appends: insertion order per list
+    idx.add_encoded(lists[n // 2:], codes[n // 2:], ids[n // 2:])
+    xq = rng.standard_normal((nq, d)).astype(np.float32) * 30
+    probe = np.stack([rng.permutation(nlist)[:nprobe] for _ in range(nq)]).astype(np.int64)
+    probe[0, 0] = 1                                                  # an empty list
+    if nprobe > 2:
+        probe[1, 1] = -1                                             # faiss convention for "no list"
+    D, I, sizes = idx.search_lists(torch.from_numpy(xq).to(_dev()), probe)
+    order = np.argsort(lists, kind="stable")                         # flat index content: list-contiguous, insertion order
+    off = np.concatenate([[0], np.cumsum(np.bincount(lists, minlength=nlist))]).astype(np.uint64)
+    Dr, Ir, sr = oracle.ivfpq_search_lists(xq, probe, cent, books, codes[order], ids[order], off)
+    assert (sizes == sr).all() and int(sizes.sum()) == Dr.size
+    assert (I.cpu().numpy() == Ir).all()
+    assert (D.cpu().numpy().view(np.uint32) == Dr.view(np.uint32)).all()
