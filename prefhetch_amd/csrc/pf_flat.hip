@@ -30,7 +30,12 @@
 
 namespace pf {
 
-constexpr int TM = 128, TN = 128, TK = 32;      // distance tile: 128 queries x 128 base rows, K slabs of 32
+#ifndef PF_TK
+#define PF_TK 32
+#endif
+constexpr int TM = 128, TN = 128, TK = PF_TK;   // distance tile: 128 queries x 128 base rows, K slabs of TK
+constexpr int KQ = TK / 4;                        // lanes covering one row of a slab (16 B each)
+constexpr int SLAB_IT = TM * KQ / 256;            // fetch/commit iterations per thread
 constexpr int LDA = TM + 1;                       // k-major LDS rows padded by one float: conflict-free transposing writes
 constexpr uint32_t SEL_CAP = 2048;                // reservoir capacity (keys); k <= SEL_CAP/2
 constexpr uint32_t SEL_THREADS = 256;
@@ -65,14 +70,14 @@ struct TileArgs {
 };
 
 // A 128-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
-// matrix pipe works on slab s: fetch (global -> registers: thread t holds row (t>>3)+32*it, k = (t&7)*4 .. +3)
+// matrix pipe works on slab s: fetch (global -> registers: thread t holds row t/KQ + (256/KQ)*it, k = (t%KQ)*4 .. +3)
 // and commit (registers -> LDS, transposed to lds[k][row]).
-__device__ __forceinline__ void slab_fetch(float4 (&v)[4], const float *__restrict__ src, size_t row0, size_t rows_valid,
+__device__ __forceinline__ void slab_fetch(float4 (&v)[SLAB_IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = (tid >> 3) + 32 * it;
-        const uint32_t k = k0 + (tid & 7) * 4;
+    for (int it = 0; it < SLAB_IT; ++it) {
+        const int row = tid / KQ + (256 / KQ) * it;
+        const uint32_t k = k0 + (tid % KQ) * 4;
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((size_t)row < rows_valid) {
             const float *p = src + (row0 + row) * (size_t)d + k;
@@ -87,11 +92,11 @@ __device__ __forceinline__ void slab_fetch(float4 (&v)[4], const float *__restri
     }
 }
 
-__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[4], int tid) {
+__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[SLAB_IT], int tid) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = (tid >> 3) + 32 * it;
-        const int kk = (tid & 7) * 4;
+    for (int it = 0; it < SLAB_IT; ++it) {
+        const int row = tid / KQ + (256 / KQ) * it;
+        const int kk = (tid % KQ) * 4;
         lds[(kk + 0) * LDA + row] = v[it].x;
         lds[(kk + 1) * LDA + row] = v[it].y;
         lds[(kk + 2) * LDA + row] = v[it].z;
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[SLAB_IT], rb[SLAB_IT];
     slab_fetch(ra, p.xq, q0, q_valid, p.d, 0, tid);
     slab_fetch(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
     for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
