@@ -12,8 +12,9 @@
  *   - Every data pointer is a DEVICE pointer (hipMalloc / pf_malloc / torch tensor data_ptr) on the
  *     device the handle was created on, unless the parameter name ends in _host or says "host or device".
  *   - `stream` is a hipStream_t passed as void* (NULL = the device's null stream).  Calls enqueue work
- *     and return; nothing synchronises unless documented.  Safe to capture into a hipGraph: no call
- *     on the compute path allocates, frees or synchronises.
+ *     and return; nothing synchronises unless documented.  The polynomial calls (NTT, dyadic, add, ct x pt)
+ *     and pf_flat_search after pf_flat_reserve never allocate, free or synchronise, so they can be
+ *     captured into a hipGraph; pf_key_switch (first call) and pf_ivfpq_search_lists say what they do.
  *   - RNS polynomial buffers: `n_limb_polys` polynomials of N uint64 coefficients, contiguous;
  *     polynomial p belongs to RNS limb (p % L).  A SEAL Ciphertext's data() -- size x L x N,
  *     poly-major, then limb, then coefficient -- and a batch of them therefore pass through unchanged.
