@@ -73,6 +73,26 @@ def test_flat_search_adversarial_order_overflow_fallback(pf):
     assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
 
 
+def test_flat_edge_cases(pf):
+    """Empty base, empty query batch, out-of-range ids: defined results, no faults."""
+    rng = np.random.default_rng(1)
+    empty = pf.FlatL2(np.zeros((0, 128), np.float32), _dev())
+    D, I = empty.search(torch.from_numpy(_sift_like(rng, 3)).to(_dev()), 5)
+    assert bool(torch.isinf(D).all()) and bool((I == -1).all())
+    base = _sift_like(rng, 300)
+    idx = pf.FlatL2(base, _dev())
+    D0, I0 = idx.search(torch.empty((0, 128), dtype=torch.float32, device=_dev()), 4)
+    assert D0.shape == (0, 4) and I0.shape == (0, 4)
+    xq = _sift_like(rng, 2)
+    ids = np.array([[0, 299, -1, 300], [5, 5, 10**12, 7]], dtype=np.int64)
+    got = idx.l2_gathered(torch.from_numpy(xq).to(_dev()), torch.from_numpy(ids).to(_dev())).cpu().numpy()
+    ok = (ids >= 0) & (ids < 300)
+    ref = oracle.precise_search(base, xq, np.where(ok, ids, 0))
+    assert (got[ok] == ref[ok]).all() and np.isinf(got[~ok]).all()
+    rows = idx.gather_rows(torch.from_numpy(ids).to(_dev())).cpu().numpy()
+    assert (rows[ok] == base[ids[ok]]).all() and np.isnan(rows[~ok]).all()
+
+
 def test_flat_search_odd_dimension(pf):
     rng = np.random.default_rng(6)
     xb, xq = _sift_like(rng, 3000, 30), _sift_like(rng, 9, 30)
