@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="encrypted queries per GPU per step")
     ap.add_argument("--nb", type=int, default=NB)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the two stages on separate HIP streams (matrix pipe vs FP64 VALU); per-stage times then overlap")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default min(16, cores))")
     return ap.parse_args()
 
@@ -113,13 +115,21 @@ def main():
     gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    side = torch.cuda.Stream(device=dev) if args.overlap else None
 
     def step(i=None):
         e = ev[i] if i is not None else None
+        if side is not None:                                       # stage B on its own stream, concurrently with stage A
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                ctx.ct_pt_mul(ct, pt, out=out)
         if e: e[0].record()
         D, I = flat.search(xq, TOPK)                               # stage A
         if e: e[1].record()
-        ctx.ct_pt_mul(ct, pt, out=out)                             # stage B (one launch)
+        if side is None:
+            ctx.ct_pt_mul(ct, pt, out=out)                         # stage B (one launch)
+        else:
+            torch.cuda.current_stream(dev).wait_stream(side)
         if e: e[2].record()
         if world > 1:                                              # stage C: one collective, packed (I, D)
             pfd.gather_topk(D, I, out=gathered)
@@ -176,6 +186,7 @@ def main():
                        "ring_dim": N_RING, "limbs": LIMBS, "batch_per_gpu": B, "nb": args.nb, "dim": DIM, "k": TOPK,
                        "parallelism": f"query-sharded x{world}, base matrix replicated"},
             "stages_ms": {"prefilter": ms_a, "ct_x_pt": ms_b, "gather": ms_c},
+            "overlapped_streams": bool(args.overlap),
             "ct_x_pt_only_qps_per_gpu": B / (ms_b * 1e-3),
             "roofline": {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -214,12 +214,12 @@ struct SelArgs {
     float *D; int64_t *I;                    // written when last
 };
 
-// in-LDS bitonic sort of SEL_CAP keys, ascending
-__device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid) {
-    for (uint32_t size = 2; size <= SEL_CAP; size <<= 1) {
+// in-LDS bitonic sort of the first n keys (n a power of two <= SEL_CAP; the rest must already be KEY_INF), ascending
+__device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n = SEL_CAP) {
+    for (uint32_t size = 2; size <= n; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (uint32_t t = tid; t < SEL_CAP / 2; t += SEL_THREADS) {
+            for (uint32_t t = tid; t < n / 2; t += SEL_THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -307,8 +307,10 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
             }
         });
     }
-    // sort, keep k, carry or emit
-    bitonic_sort(keys, tid);
+    // sort, keep k, carry or emit (a merge usually holds far fewer than SEL_CAP keys: sort only what is there)
+    uint32_t n_sort = SEL_CAP;
+    if (merge) { n_sort = 64; while (n_sort < c0 + nc) n_sort <<= 1; }
+    bitonic_sort(keys, tid, n_sort);
     const uint32_t total = cnt < k ? cnt : k;
     if (p.last) {
         for (uint32_t i = tid; i < k; i += SEL_THREADS) {
