@@ -90,12 +90,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device; there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PF_BENCH_SINGLE_DEVICE=1 + PF_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a one-GPU box
+    # (all ranks on cuda:0, collectives over gloo); never used for reported numbers
+    rehearsal = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import prefhetch_amd as pf
     from prefhetch_amd import dist as pfd
@@ -169,7 +177,7 @@ def main():
         tf = flops / (ms_a * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and B == 1024:                     # the PMC record is for the default batch
             try:
                 traffic = json.load(open(tpath)).get("k_ctpt_bytes_per_launch")
             except Exception:
@@ -179,9 +187,9 @@ def main():
             "value": total_q / (elapsed / args.steps), "unit": "encrypted queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (exact-FP64 butterflies) + f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE config 3 per GPU: flat-L2 top-200 pre-filter of 1024 queries over 1M x 128 fp32 "
-                                   "+ fused ct x pt (N=8192, 4 limbs, batch 1024, coefficient form in and out)"
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
+            "config": {"workload": f"BASELINE config 3 per GPU: flat-L2 top-{TOPK} pre-filter of {B} queries over {args.nb} x {DIM} fp32 "
+                                   f"+ fused ct x pt (N=8192, 4 limbs, batch {B}, coefficient form in and out)"
                                    + (" + one RCCL all-gather of packed top-k" if world > 1 else ""),
                        "ring_dim": N_RING, "limbs": LIMBS, "batch_per_gpu": B, "nb": args.nb, "dim": DIM, "k": TOPK,
                        "parallelism": f"query-sharded x{world}, base matrix replicated"},
@@ -191,7 +199,7 @@ def main():
             "roofline": {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_b},
-            "roofline_prefilter": {"kernel": "k_l2_tile (+ k_select_chunk), whole stage", "bound": "mfma", "achieved": tf,
+            "roofline_prefilter": {"kernel": "k_l2_tile (+ k_select), whole stage", "bound": "mfma", "achieved": tf,
                                    "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TF,
                                    "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b},
         }
