@@ -164,6 +164,85 @@ int main(int argc, char **argv) {
         EXPECT(total == s.size() && total > 0);
     }
 
+    // ---- the whole 4-round protocol of the reference client (src/client/client.cpp:7-80) against this Server, on
+    // clustered synthetic data, scored like benchmark_results (src/client/client_lib.cpp:243-337): Recall@k and MRR@k
+    // against exact ground truth.  SIFT is not available offline; a Gaussian mixture stands in for it.
+    if (gaussian) {
+        std::mt19937 r2(7);
+        std::normal_distribution<float> unit(0.f, 1.f);
+        const int n_clusters = 64;
+        std::vector<float> centers(n_clusters * 128);
+        for (float &v : centers) v = 40.f * unit(r2);
+        auto sample = [&](float *dst) {
+            const int c = static_cast<int>(r2() % n_clusters);
+            for (int t = 0; t < 128; t++) dst[t] = centers[c * 128 + t] + 4.f * unit(r2);
+        };
+        std::vector<float> b2(static_cast<size_t>(NBASE) * 128), t2v(NT * 128);
+        for (size_t i = 0; i < static_cast<size_t>(NBASE); i++) sample(b2.data() + i * 128);
+        for (size_t i = 0; i < NT; i++) sample(t2v.data() + i * 128);
+        Q q2;
+        for (auto &q : q2) sample(q.data());
+        srv->init_from_memory(b2.data(), NBASE, t2v.data(), NT);
+        // round 1: centroids -> client-side shortlist of NPROBE lists (client_lib.cpp:50-81,100-102)
+        std::vector<std::array<float, 128>> cents;
+        srv->retrieve_centroids(cents);
+        std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> probe;
+        for (int i = 0; i < NQUERY; i++) {
+            std::vector<std::pair<float, int64_t>> all;
+            for (int j = 0; j < NLIST; j++) {
+                float distance = 0.0;
+                for (int k = 0; k < 128; k++) distance += std::pow(q2[i][k] - cents[j][k], 2);
+                all.push_back({distance, j});
+            }
+            std::sort(all.begin(), all.end());
+            for (int j = 0; j < NPROBE; j++) probe[i][j] = all[j].second;
+        }
+        // round 2: coarse scores -> top COARSE_PROBE per query (client_lib.cpp:122-156)
+        std::vector<float> cs; std::vector<faiss::idx_t> ci; std::array<size_t, NQUERY> sz{};
+        srv->coarseSearch(q2, probe, cs, ci, sz);
+        std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> coarse_ids;
+        size_t at = 0;
+        bool enough = true;
+        for (int i = 0; i < NQUERY; i++) {
+            std::vector<std::pair<float, int64_t>> v;
+            for (size_t j = 0; j < sz[i]; j++) v.push_back({cs[at + j], ci[at + j]});
+            at += sz[i];
+            std::sort(v.begin(), v.end());
+            if (v.size() < static_cast<size_t>(COARSE_PROBE)) { enough = false; break; }
+            for (int j = 0; j < COARSE_PROBE; j++) coarse_ids[i][j] = v[j].second;
+        }
+        EXPECT(enough);
+        if (enough) {
+            // round 3: exact distances of the shortlist -> top K (client_lib.cpp:158-207)
+            std::array<std::array<float, COARSE_PROBE>, NQUERY> pd;
+            srv->preciseSearch(q2, coarse_ids, pd);
+            double recall_at[3] = {0, 0, 0}, mrr10 = 0;
+            const int ks[3] = {1, 10, 100};
+            for (int i = 0; i < NQUERY; i++) {
+                std::vector<std::pair<float, int64_t>> v;
+                for (int j = 0; j < COARSE_PROBE; j++) v.push_back({pd[i][j], coarse_ids[i][j]});
+                std::sort(v.begin(), v.end());
+                std::vector<std::pair<double, int64_t>> gt;                      // exact ground truth
+                for (int64_t j = 0; j < NBASE; j++) {
+                    double dd = 0;
+                    for (int t = 0; t < 128; t++) { const double df = double(b2[j * 128 + t]) - double(q2[i][t]); dd += df * df; }
+                    gt.push_back({dd, j});
+                }
+                std::sort(gt.begin(), gt.end());
+                for (int a = 0; a < 3; a++) {
+                    int hit = 0;
+                    for (int x = 0; x < ks[a]; x++)
+                        for (int y = 0; y < ks[a]; y++) if (v[x].second == gt[y].second) { ++hit; break; }
+                    recall_at[a] += double(hit) / ks[a] / NQUERY;
+                }
+                for (int x = 0; x < 10; x++) if (v[x].second == gt[0].second) { mrr10 += 1.0 / (x + 1) / NQUERY; break; }
+            }
+            std::printf("protocol on a 64-cluster Gaussian mixture: Recall@1 %.3f Recall@10 %.3f Recall@100 %.3f MRR@10 %.3f\n",
+                        recall_at[0], recall_at[1], recall_at[2], mrr10);
+            EXPECT(recall_at[1] >= 0.9 && recall_at[2] >= 0.8 && mrr10 >= 0.9);
+        }
+    }
+
     Timer t; long long us = -1, ms = -1;
     t.StartTimer(); t.StopTimer(); t.getDuration(us, ms);
     EXPECT(us >= 0 && ms >= 0);
