@@ -171,3 +171,47 @@ def test_key_switch_oracle_a_vs_bigint():
                            [[[0] * N for _ in range(L)] for _ in range(2)], qs, psis)
     assert (o.key_switch(tsum.reshape(1, L, N), ksk, zero).reshape(2, L, N) == np.array(ref_sum, dtype=np.uint64)).all()
     assert a.shape == b.shape
+
+
+def test_barrett_dyadic_against_python_modulo():
+    """SURVEY 8c known-answer test 7: 128->64 Barrett product vs Python's %, including operands q-1, for every
+    BFVDefault prime (27 to 56 bits)."""
+    rng = np.random.default_rng(77)
+    for N, qs in oracle.BFV_DEFAULT.items():
+        for q in qs:
+            o = oracle.Oracle(N, [q]) if (q - 1) % (2 * N) == 0 else None
+            if o is None:
+                continue
+            a = rng.integers(0, q, N, dtype=np.uint64)
+            b = rng.integers(0, q, N, dtype=np.uint64)
+            a[:4] = [q - 1, q - 1, 0, 1]
+            b[:4] = [q - 1, 1, q - 1, q - 1]
+            got = o.dyadic_mul(a, b)
+            assert [int(x) for x in got[:64]] == [int(x) * int(y) % q for x, y in zip(a[:64], b[:64])]
+            assert int(got[0]) == (q - 1) * (q - 1) % q
+
+
+try:
+    from hypothesis import given, settings, strategies as st
+    _HAVE_HYPOTHESIS = True
+except Exception:        # pragma: no cover
+    _HAVE_HYPOTHESIS = False
+
+
+if _HAVE_HYPOTHESIS:
+    _PRIMES_N64 = [q for qs in oracle.BFV_DEFAULT.values() for q in qs if (q - 1) % 128 == 0]
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.sampled_from(_PRIMES_N64), st.integers(0, 2**32 - 1))
+    def test_hypothesis_random_polys_oracle_a_vs_b(q, seed):
+        """SURVEY 8c known-answer test 6: random polynomials per prime, lazy-butterfly C oracle against the direct
+        big-integer evaluation (N = 64 keeps the O(N^2) side fast)."""
+        N = 64
+        rng = np.random.default_rng(seed)
+        o = oracle.Oracle(N, [q])
+        a = rng.integers(0, q, N, dtype=np.uint64)
+        b = rng.integers(0, q, N, dtype=np.uint64)
+        A = o.ntt_forward(a)
+        assert [int(x) for x in A] == B.ntt_direct([int(x) for x in a], q, o.psi(0))
+        prod = o.ntt_inverse(o.dyadic_mul(A, o.ntt_forward(b)))
+        assert [int(x) for x in prod] == B.negacyclic_mul([int(x) for x in a], [int(x) for x in b], q)
