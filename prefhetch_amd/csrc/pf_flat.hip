@@ -25,6 +25,7 @@
 // Keys order by (distance, id), which fixes the tie order faiss leaves undefined.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cstdlib>
 #include <string>
 #include "pf_common.hpp"
 
@@ -33,10 +34,8 @@ namespace pf {
 #ifndef PF_TK
 #define PF_TK 32
 #endif
-constexpr int TM = 128, TN = 128, TK = PF_TK;   // distance tile: 128 queries x 128 base rows, K slabs of TK
+constexpr int TK = PF_TK;                         // K slab depth of the distance tiles
 constexpr int KQ = TK / 4;                        // lanes covering one row of a slab (16 B each)
-constexpr int SLAB_IT = TM * KQ / 256;            // fetch/commit iterations per thread
-constexpr int LDA = TM + 1;                       // k-major LDS rows padded by one float: conflict-free transposing writes
 constexpr uint32_t SEL_CAP = 2048;                // reservoir capacity (keys); k <= SEL_CAP/2
 constexpr uint32_t SEL_THREADS = 256;
 constexpr uint64_t KEY_INF = 0x7F800000FFFFFFFFull;   // (+inf, id 2^32-1): sorts after every real key
@@ -69,14 +68,26 @@ struct TileArgs {
     uint32_t n_qtiles;
 };
 
-// A 128-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
-// matrix pipe works on slab s: fetch (global -> registers: thread t holds row t/KQ + (256/KQ)*it, k = (t%KQ)*4 .. +3)
+// Tile geometry: WAVES = 4 -> 128 x 128 tile, 256 threads, each wave a 64 x 64 quadrant; WAVES = 1 -> one wave owns a
+// whole 64 x 64 tile (no workgroup barrier at all: waves drift apart instead of marching in lockstep).
+template <int WAVES>
+struct TileGeo {
+    static constexpr int T = WAVES == 4 ? 128 : 64;          // tile edge (queries and base rows)
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int ROWS_PER_IT = THREADS / KQ;
+    static constexpr int IT = T / ROWS_PER_IT;                // fetch/commit iterations per thread
+    static constexpr int LD = T + 1;                          // k-major LDS rows padded by one float
+};
+
+// A T-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
+// matrix pipe works on slab s: fetch (global -> registers: thread t holds row t/KQ + ROWS_PER_IT*it, k = (t%KQ)*4 .. +3)
 // and commit (registers -> LDS, transposed to lds[k][row]).
-__device__ __forceinline__ void slab_fetch(float4 (&v)[SLAB_IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
+template <class GEO>
+__device__ __forceinline__ void slab_fetch(float4 (&v)[GEO::IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
 #pragma unroll
-    for (int it = 0; it < SLAB_IT; ++it) {
-        const int row = tid / KQ + (256 / KQ) * it;
+    for (int it = 0; it < GEO::IT; ++it) {
+        const int row = tid / KQ + GEO::ROWS_PER_IT * it;
         const uint32_t k = k0 + (tid % KQ) * 4;
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((size_t)row < rows_valid) {
@@ -92,59 +103,62 @@ __device__ __forceinline__ void slab_fetch(float4 (&v)[SLAB_IT], const float *__
     }
 }
 
-__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[SLAB_IT], int tid) {
+template <class GEO>
+__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[GEO::IT], int tid) {
 #pragma unroll
-    for (int it = 0; it < SLAB_IT; ++it) {
-        const int row = tid / KQ + (256 / KQ) * it;
+    for (int it = 0; it < GEO::IT; ++it) {
+        const int row = tid / KQ + GEO::ROWS_PER_IT * it;
         const int kk = (tid % KQ) * 4;
-        lds[(kk + 0) * LDA + row] = v[it].x;
-        lds[(kk + 1) * LDA + row] = v[it].y;
-        lds[(kk + 2) * LDA + row] = v[it].z;
-        lds[(kk + 3) * LDA + row] = v[it].w;
+        lds[(kk + 0) * GEO::LD + row] = v[it].x;
+        lds[(kk + 1) * GEO::LD + row] = v[it].y;
+        lds[(kk + 2) * GEO::LD + row] = v[it].z;
+        lds[(kk + 3) * GEO::LD + row] = v[it].w;
     }
 }
 
-template <bool FILTER>
-__global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
-    __shared__ float sA[TK * LDA];
-    __shared__ float sB[TK * LDA];
+template <bool FILTER, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) k_l2_tile(TileArgs p) {
+    using GEO = TileGeo<WAVES>;
+    constexpr int T = GEO::T, LD = GEO::LD;
+    __shared__ float sA[TK * LD];
+    __shared__ float sB[TK * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
-    // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the 64 KiB base tile is
+    // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the base tile is
     // fetched from HBM once into that XCD's L2 and re-read from there by the other query tiles.
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const uint32_t qt = j % p.n_qtiles, ct = (j / p.n_qtiles) * 8 + xcd;
-    const size_t q0 = (size_t)qt * TM;
-    const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
+    const size_t q0 = (size_t)qt * T;
+    const size_t c0 = (size_t)ct * T;                          // column inside the chunk
     if (c0 >= p.nb_count) return;
-    const size_t q_valid = p.nq - q0 < TM ? p.nq - q0 : TM;
-    const size_t c_valid = p.nb_count - c0 < TN ? p.nb_count - c0 : TN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const size_t q_valid = p.nq - q0 < (size_t)T ? p.nq - q0 : (size_t)T;
+    const size_t c_valid = p.nb_count - c0 < (size_t)T ? p.nb_count - c0 : (size_t)T;
+    const int wm = WAVES == 4 ? (wave >> 1) * 64 : 0, wn = WAVES == 4 ? (wave & 1) * 64 : 0;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    float4 ra[SLAB_IT], rb[SLAB_IT];
-    slab_fetch(ra, p.xq, q0, q_valid, p.d, 0, tid);
-    slab_fetch(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
+    float4 ra[GEO::IT], rb[GEO::IT];
+    slab_fetch<GEO>(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch<GEO>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
     for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
         __syncthreads();                               // the previous slab's fragment reads are done
-        slab_commit(sA, ra, tid);
-        slab_commit(sB, rb, tid);
+        slab_commit<GEO>(sA, ra, tid);
+        slab_commit<GEO>(sB, rb, tid);
         __syncthreads();
         if (k0 + TK < p.d) {                           // next slab's loads fly under this slab's MFMAs
-            slab_fetch(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
-            slab_fetch(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
+            slab_fetch<GEO>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
+            slab_fetch<GEO>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 2) {
             const int k = ks + (lane >> 5);
-            const float a0 = sA[k * LDA + wm + (lane & 31)], a1 = sA[k * LDA + wm + 32 + (lane & 31)];
-            const float b0 = sB[k * LDA + wn + (lane & 31)], b1 = sB[k * LDA + wn + 32 + (lane & 31)];
+            const float a0 = sA[k * LD + wm + (lane & 31)], a1 = sA[k * LD + wm + 32 + (lane & 31)];
+            const float b0 = sB[k * LD + wn + (lane & 31)], b1 = sB[k * LD + wn + 32 + (lane & 31)];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -153,21 +167,21 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
     }
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     if constexpr (FILTER) {
-        // per-query norm and threshold of this tile's 128 rows, staged in LDS (sA is free now)
+        // per-query norm and threshold of this tile's rows, staged in LDS (sA is free now)
         __syncthreads();
-        if (tid < TM) {
+        if (tid < T) {
             const bool ok = q0 + tid < p.nq;
             sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
-            sA[TM + tid] = ok ? p.tau[q0 + tid] : -1.f;            // -1: nothing passes (distances are >= 0)
+            sA[T + tid] = ok ? p.tau[q0 + tid] : -1.f;              // -1: nothing passes (distances are >= 0)
         }
         __syncthreads();
     }
     size_t col[2]; bool col_ok[2]; float bnv[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        col[j] = c0 + wn + 32 * j + (lane & 31);
-        col_ok[j] = col[j] < p.nb_count;
-        bnv[j] = col_ok[j] ? p.bn[p.nb_first + col[j]] : 0.f;
+    for (int jj = 0; jj < 2; ++jj) {
+        col[jj] = c0 + wn + 32 * jj + (lane & 31);
+        col_ok[jj] = col[jj] < p.nb_count;
+        bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -176,24 +190,24 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile(TileArgs p) {
             const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const size_t row = q0 + lrow;
             if constexpr (FILTER) {
-                const float qnv = sA[lrow], tv = sA[TM + lrow];
+                const float qnv = sA[lrow], tv = sA[T + lrow];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float dist = fmaf(-2.f, acc[i][j][r], qnv + bnv[j]);
+                for (int jj = 0; jj < 2; ++jj) {
+                    float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
                     dist = dist < 0.f ? 0.f : dist;
-                    if (col_ok[j] && dist <= tv) {                   // ties pass; k_select orders by (distance, id)
+                    if (col_ok[jj] && dist <= tv) {                   // ties pass; k_select orders by (distance, id)
                         const uint32_t pos = atomicAdd(&p.cand_cnt[row], 1u);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col[j]));
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col[jj]));
                     }
                 }
             } else if (row < p.nq) {
                 const float qnv = p.qn[row];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (!col_ok[j]) continue;
-                    float dist = fmaf(-2.f, acc[i][j][r], qnv + bnv[j]);
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (!col_ok[jj]) continue;
+                    float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
                     dist = dist < 0.f ? 0.f : dist;
-                    p.slab[row * p.slab_ld + col[j]] = dist;
+                    p.slab[row * p.slab_ld + col[jj]] = dist;
                 }
             }
         }
@@ -495,12 +509,23 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
     a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I;
-    t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
-    auto tile_grid = [&](size_t cols) { const size_t nct = (cols + TN - 1) / TN; return dim3((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles)); };
+    static const int tile_waves = getenv("PF_TILE_WG_WAVES") ? atoi(getenv("PF_TILE_WG_WAVES")) : 4;   // tuning knob: 4 or 1
+    const size_t TT = tile_waves == 1 ? 64 : 128;
+    t.n_qtiles = (uint32_t)((nq + TT - 1) / TT);
+    auto tile_grid = [&](size_t cols) { const size_t nct = (cols + TT - 1) / TT; return dim3((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles)); };
+    auto launch_tile = [&](bool filter, size_t cols) {
+        if (tile_waves == 1) {
+            if (filter) hipLaunchKernelGGL((k_l2_tile<true, 1>), tile_grid(cols), dim3(64), 0, s, t);
+            else hipLaunchKernelGGL((k_l2_tile<false, 1>), tile_grid(cols), dim3(64), 0, s, t);
+        } else {
+            if (filter) hipLaunchKernelGGL((k_l2_tile<true, 4>), tile_grid(cols), dim3(256), 0, s, t);
+            else hipLaunchKernelGGL((k_l2_tile<false, 4>), tile_grid(cols), dim3(256), 0, s, t);
+        }
+    };
     // bootstrap chunk through the slab
     const size_t boot = f->nb < w.boot ? f->nb : w.boot;
     t.nb_first = 0; t.nb_count = boot;
-    if (boot) hipLaunchKernelGGL(k_l2_tile<false>, tile_grid(boot), dim3(256), 0, s, t);
+    if (boot) launch_tile(false, boot);
     a.nb_first = 0; a.nb_count = boot; a.mode = 0; a.first = 1; a.last = boot == f->nb;
     hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
     // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a quarter of
@@ -508,12 +533,12 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     size_t pos = boot;
     while (pos < f->nb) {
         size_t chunk = pos * w.cap / (4 * (size_t)k);
-        chunk = chunk / TN * TN;
+        chunk = chunk / 128 * 128;
         if (chunk < 4096) chunk = 4096;
         if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
         if (chunk > f->nb - pos) chunk = f->nb - pos;
         t.nb_first = pos; t.nb_count = chunk;
-        hipLaunchKernelGGL(k_l2_tile<true>, tile_grid(chunk), dim3(256), 0, s, t);
+        launch_tile(true, chunk);
         a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
         hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
         pos += chunk;
