@@ -163,6 +163,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # PCIe note (never part of `value`): one batch's ciphertexts + plaintexts host -> HBM and results back, pinned memory
+    pcie = None
+    if rank == 0 and world == 1:
+        try:
+            h_in = torch.empty(ct.numel() + pt.numel(), dtype=torch.int64).pin_memory()
+            h_out = torch.empty(out.numel(), dtype=torch.int64).pin_memory()
+            d_in = torch.empty_like(h_in, device=dev)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            d_in.copy_(h_in, non_blocking=True)                      # warm-up
+            torch.cuda.synchronize()
+            e0.record(); d_in.copy_(h_in, non_blocking=True); e1.record(); h_out.copy_(out.view(-1), non_blocking=True); e2.record()
+            torch.cuda.synchronize()
+            pcie = {"h2d_ms": e0.elapsed_time(e1), "d2h_ms": e1.elapsed_time(e2), "h2d_bytes": h_in.numel() * 8, "d2h_bytes": h_out.numel() * 8}
+            del h_in, h_out, d_in
+        except Exception as ex:                                   # pinned allocation can fail on small hosts
+            pcie = {"error": str(ex)}
+
     ms_a = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_b = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ms_c = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
@@ -198,11 +215,16 @@ def main():
             "ct_x_pt_only_qps_per_gpu": B / (ms_b * 1e-3),
             "roofline": {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_measured_copy_6290": ach / 6290.0,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_b},
             "roofline_prefilter": {"kernel": "k_l2_tile (+ k_select), whole stage", "bound": "mfma", "achieved": tf,
                                    "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TF,
                                    "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b},
         }
+        if pcie:
+            if "h2d_ms" in pcie:
+                pcie["queries_per_s_if_inputs_and_outputs_crossed_pcie"] = B / ((ms_per_step + pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
+            res["pcie_note"] = pcie
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             res["cpu_baseline"] = cpu_baseline(threads)
