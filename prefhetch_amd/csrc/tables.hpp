@@ -42,7 +42,7 @@ struct LimbTables {
     uint64_t ratio0 = 0, ratio1 = 0;              // floor(2^128/q)
     bool f64_ok = false;                          // q small enough for the exact-FP64 back-end
     std::vector<TwU64> fwd_u, inv_u;              // N entries each, entry 0 of inv_u = N^-1, entry 1 = psi^-bitrev(1)*N^-1
-    std::vector<TwF64> fwd_f, inv_f;              // the same twiddles as doubles (8 bytes per entry), then 32 quotients
+    std::vector<TwF64> fwd_f, inv_f;              // the same twiddles as doubles (8 bytes per entry), then 64 quotients
 };
 
 // Bound for ArithF64 (see ntt_core.hpp): R*q <= 2^50 (R = coefficients per thread: an inverse pass doubles R/2.. times
@@ -95,10 +95,10 @@ inline bool build_limb_tables(uint32_t N, uint64_t q, LimbTables &t, std::string
             t.fwd_f[j] = TwF64{(double)fw[j]};
             t.inv_f[j] = TwF64{(double)iw[j]};
         }
-        // entries N .. N+31: the quotient estimates fl(w * fl(1/q)) of entries 0 .. 31, exactly as the device
+        // entries N .. N+63: the quotient estimates fl(w * fl(1/q)) of entries 0 .. 63 (R <= 64 registers per thread), exactly as the device
         // would compute them, for the workgroup-uniform twiddles of pass 0 (ntt_core.hpp, PassTw)
         const double qinv = 1.0 / (double)q;
-        for (uint32_t j = 0; j < 32; ++j) {
+        for (uint32_t j = 0; j < 64; ++j) {
             t.fwd_f.push_back(TwF64{j < N ? (double)fw[j] * qinv : 0.0});
             t.inv_f.push_back(TwF64{j < N ? (double)iw[j] * qinv : 0.0});
         }

@@ -42,6 +42,7 @@ CONFIGS = [  # (N, moduli, force_u64)
     (16384, [0x7FFFFFFFE90001, 0x7FFFFFD8001], False),  # mixed widths -> u64 path
     (16384, [0x7FFFFFD8001, 0x7FFFFFC8001], False),      # exact-FP64 path at N=16384
     (32768, oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:], False),   # config 5 ring: 55/56-bit primes, u64 path
+    (32768, [0x7FFFFDB0001, 0x7FFFFD20001], False),          # 43-bit primes at N=32768: exact-FP64 path, 64 coefficients per thread
 ]
 
 

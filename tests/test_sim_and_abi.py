@@ -21,7 +21,7 @@ SIM_CASES = [  # (logn, q, arithmetic) 0 = exact-FP64, 1 = u64 Shoup
     (12, 0xFFFFEE001, 0), (12, 0x1FFFFE0001, 1),
     (13, 0x7FFFFFD8001, 0), (13, 0xFFFFFEBC001, 0), (13, 0xFFFFFFFC001, 1),
     (11, 0x3FFFFFFF000001, 1), (13, 0x7FFFFFFFE90001, 1), (14, 0x7FFFFFFFE90001, 1),
-    (15, 0x7FFFFFFFE90001, 1), (15, 0xFFFFFFFFF70001, 1),
+    (15, 0x7FFFFFFFE90001, 1), (15, 0xFFFFFFFFF70001, 1), (15, 0x7FFFFDB0001, 0),    # last: exact-FP64 at N = 32768
 ]
 
 
