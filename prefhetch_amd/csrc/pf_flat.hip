@@ -17,7 +17,7 @@
 //              when it fills -- faiss ReservoirTopN does the same on the CPU for k >= 100).  This yields each
 //              query's running top-k and its k-th distance tau.
 //   streaming  the rest of the base is processed in geometrically growing chunks whose tile kernel FILTERS in its
-//              epilogue: only distances <= tau are appended (one atomic per survivor) to the query's candidate
+//              epilogue: only distances <= tau are appended (ballot + one atomic per half-wave) to the query's candidate
 //              list -- expected k * chunk / rows_seen survivors -- and k_select merges them into the running
 //              top-k and tightens tau.  No distance slab is written or re-read.  If a candidate list overflows
 //              (adversarial row order), k_select re-derives that query's chunk exactly by recomputing the
@@ -68,26 +68,34 @@ struct TileArgs {
     uint32_t n_qtiles;
 };
 
-// Tile geometry: WAVES = 4 -> 128 x 128 tile, 256 threads, each wave a 64 x 64 quadrant; WAVES = 1 -> one wave owns a
-// whole 64 x 64 tile (no workgroup barrier at all: waves drift apart instead of marching in lockstep).
-template <int WAVES>
+// Tile geometry: TM queries x TN base rows per workgroup of 256 threads (4 waves laid out WM x WN); a wave owns
+// MI x NJ MFMA blocks of 32 x 32.
+//   128 x 128 (2 x 2 waves, 2 x 2 blocks)   the batch geometry: every operand value fetched from LDS feeds two MFMAs
+//   TM = 32 / 64, TN = 256 (1 x 4 waves)    small batches: a 128-row tile would spend 4x / 2x the matrix work on
+//                                           padding rows and turn an HBM-bound scan of the base into an MFMA-bound one
+template <int TM_, int TN_, int WM_, int WN_>
 struct TileGeo {
-    static constexpr int T = WAVES == 4 ? 128 : 64;          // tile edge (queries and base rows)
-    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TM = TM_, TN = TN_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int MI = TM / (32 * WM), NJ = TN / (32 * WN);   // MFMA blocks per wave
     static constexpr int ROWS_PER_IT = THREADS / KQ;
-    static constexpr int IT = T / ROWS_PER_IT;                // fetch/commit iterations per thread
-    static constexpr int LD = T + 1;                          // k-major LDS rows padded by one float
+    static constexpr int ITA = TM / ROWS_PER_IT, ITB = TN / ROWS_PER_IT;   // fetch/commit iterations per thread
+    static constexpr int LDA = TM + 1, LDB = TN + 1;                 // k-major LDS rows padded by one float
+    static_assert(THREADS == 256 && ITA >= 1 && ITB >= 1 && MI >= 1 && NJ >= 1, "unsupported tile geometry");
 };
+using GeoBatch = TileGeo<128, 128, 2, 2>;
+using GeoSmall64 = TileGeo<64, 256, 1, 4>;
+using GeoSmall32 = TileGeo<32, 256, 1, 4>;
 
-// A T-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
+// A ROWS-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
 // matrix pipe works on slab s: fetch (global -> registers: thread t holds row t/KQ + ROWS_PER_IT*it, k = (t%KQ)*4 .. +3)
 // and commit (registers -> LDS, transposed to lds[k][row]).
-template <class GEO>
-__device__ __forceinline__ void slab_fetch(float4 (&v)[GEO::IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
+template <int IT, int ROWS_PER_IT>
+__device__ __forceinline__ void slab_fetch(float4 (&v)[IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
 #pragma unroll
-    for (int it = 0; it < GEO::IT; ++it) {
-        const int row = tid / KQ + GEO::ROWS_PER_IT * it;
+    for (int it = 0; it < IT; ++it) {
+        const int row = tid / KQ + ROWS_PER_IT * it;
         const uint32_t k = k0 + (tid % KQ) * 4;
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((size_t)row < rows_valid) {
@@ -103,107 +111,129 @@ __device__ __forceinline__ void slab_fetch(float4 (&v)[GEO::IT], const float *__
     }
 }
 
-template <class GEO>
-__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[GEO::IT], int tid) {
+template <int IT, int ROWS_PER_IT, int LD>
+__device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], int tid) {
 #pragma unroll
-    for (int it = 0; it < GEO::IT; ++it) {
-        const int row = tid / KQ + GEO::ROWS_PER_IT * it;
+    for (int it = 0; it < IT; ++it) {
+        const int row = tid / KQ + ROWS_PER_IT * it;
         const int kk = (tid % KQ) * 4;
-        lds[(kk + 0) * GEO::LD + row] = v[it].x;
-        lds[(kk + 1) * GEO::LD + row] = v[it].y;
-        lds[(kk + 2) * GEO::LD + row] = v[it].z;
-        lds[(kk + 3) * GEO::LD + row] = v[it].w;
+        lds[(kk + 0) * LD + row] = v[it].x;
+        lds[(kk + 1) * LD + row] = v[it].y;
+        lds[(kk + 2) * LD + row] = v[it].z;
+        lds[(kk + 3) * LD + row] = v[it].w;
     }
 }
 
-template <bool FILTER, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2) k_l2_tile(TileArgs p) {
-    using GEO = TileGeo<WAVES>;
-    constexpr int T = GEO::T, LD = GEO::LD;
-    __shared__ float sA[TK * LD];
-    __shared__ float sB[TK * LD];
+template <bool FILTER, class GEO>
+__global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
+    constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
+    __shared__ float sA[TK * LDA];
+    __shared__ float sB[TK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
     // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the base tile is
     // fetched from HBM once into that XCD's L2 and re-read from there by the other query tiles.
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const uint32_t qt = j % p.n_qtiles, ct = (j / p.n_qtiles) * 8 + xcd;
-    const size_t q0 = (size_t)qt * T;
-    const size_t c0 = (size_t)ct * T;                          // column inside the chunk
+    const size_t q0 = (size_t)qt * TM;
+    const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
     if (c0 >= p.nb_count) return;
-    const size_t q_valid = p.nq - q0 < (size_t)T ? p.nq - q0 : (size_t)T;
-    const size_t c_valid = p.nb_count - c0 < (size_t)T ? p.nb_count - c0 : (size_t)T;
-    const int wm = WAVES == 4 ? (wave >> 1) * 64 : 0, wn = WAVES == 4 ? (wave & 1) * 64 : 0;
-    f32x16 acc[2][2];
+    const size_t q_valid = p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM;
+    const size_t c_valid = p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN;
+    const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    float4 ra[GEO::IT], rb[GEO::IT];
-    slab_fetch<GEO>(ra, p.xq, q0, q_valid, p.d, 0, tid);
-    slab_fetch<GEO>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
+    float4 ra[GEO::ITA], rb[GEO::ITB];
+    slab_fetch<GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch<GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
     for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
         __syncthreads();                               // the previous slab's fragment reads are done
-        slab_commit<GEO>(sA, ra, tid);
-        slab_commit<GEO>(sB, rb, tid);
+        slab_commit<GEO::ITA, RPI, LDA>(sA, ra, tid);
+        slab_commit<GEO::ITB, RPI, LDB>(sB, rb, tid);
         __syncthreads();
         if (k0 + TK < p.d) {                           // next slab's loads fly under this slab's MFMAs
-            slab_fetch<GEO>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
-            slab_fetch<GEO>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
+            slab_fetch<GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
+            slab_fetch<GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 2) {
             const int k = ks + (lane >> 5);
-            const float a0 = sA[k * LD + wm + (lane & 31)], a1 = sA[k * LD + wm + 32 + (lane & 31)];
-            const float b0 = sB[k * LD + wn + (lane & 31)], b1 = sB[k * LD + wn + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = sA[k * LDA + wm + 32 * i + (lane & 31)];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) b[jj] = sB[k * LDB + wn + 32 * jj + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
         }
     }
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     if constexpr (FILTER) {
         // per-query norm and threshold of this tile's rows, staged in LDS (sA is free now)
         __syncthreads();
-        if (tid < T) {
+        if (tid < TM) {
             const bool ok = q0 + tid < p.nq;
             sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
-            sA[T + tid] = ok ? p.tau[q0 + tid] : -1.f;              // -1: nothing passes (distances are >= 0)
+            sA[TM + tid] = ok ? p.tau[q0 + tid] : -1.f;             // -1: nothing passes (distances are >= 0)
         }
         __syncthreads();
     }
-    size_t col[2]; bool col_ok[2]; float bnv[2];
+    size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < NJ; ++jj) {
         col[jj] = c0 + wn + 32 * jj + (lane & 31);
         col_ok[jj] = col[jj] < p.nb_count;
         bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const size_t row = q0 + lrow;
             if constexpr (FILTER) {
-                const float qnv = sA[lrow], tv = sA[T + lrow];
+                // A half-wave holds 32 columns of ONE query per register: survivors (ties pass; k_select orders by
+                // (distance, id)) are counted with a ballot and appended with one atomic per half-wave.
+                const float qnv = sA[lrow], tv = sA[TM + lrow];
+                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
+                bool any = false;
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                    dist = dist < 0.f ? 0.f : dist;
-                    if (col_ok[jj] && dist <= tv) {                   // ties pass; k_select orders by (distance, id)
-                        const uint32_t pos = atomicAdd(&p.cand_cnt[row], 1u);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist, (uint32_t)(p.nb_first + col[jj]));
+                for (int jj = 0; jj < NJ; ++jj) {
+                    dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
+                    dist[jj] = dist[jj] < 0.f ? 0.f : dist[jj];
+                    pass[jj] = col_ok[jj] && dist[jj] <= tv;
+                    const uint64_t m = __ballot(pass[jj]);
+                    any |= m != 0;
+                    hm[jj] = (uint32_t)(m >> (lane & 32));
+                }
+                if (!any) continue;                                  // wave-uniform: the common case in large batches
+                uint32_t tot = 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) tot += __popc(hm[jj]);
+                uint32_t base = 0;
+                if ((lane & 31) == 0 && tot) base = atomicAdd(&p.cand_cnt[row], tot);
+                base = __shfl(base, lane & 32);
+                const uint32_t below = (1u << (lane & 31)) - 1u;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    if (pass[jj]) {
+                        const uint32_t pos = base + __popc(hm[jj] & below);
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj], (uint32_t)(p.nb_first + col[jj]));
                     }
+                    base += __popc(hm[jj]);
                 }
             } else if (row < p.nq) {
                 const float qnv = p.qn[row];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
+                for (int jj = 0; jj < NJ; ++jj) {
                     if (!col_ok[jj]) continue;
                     float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
                     dist = dist < 0.f ? 0.f : dist;
@@ -509,17 +539,21 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
     a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I;
-    static const int tile_waves = getenv("PF_TILE_WG_WAVES") ? atoi(getenv("PF_TILE_WG_WAVES")) : 4;   // tuning knob: 4 or 1
-    const size_t TT = tile_waves == 1 ? 64 : 128;
-    t.n_qtiles = (uint32_t)((nq + TT - 1) / TT);
-    auto tile_grid = [&](size_t cols) { const size_t nct = (cols + TT - 1) / TT; return dim3((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles)); };
+    // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
+    // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
+    const int geo = nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
+    const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = geo == 2 ? 128 : 256;
+    t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
     auto launch_tile = [&](bool filter, size_t cols) {
-        if (tile_waves == 1) {
-            if (filter) hipLaunchKernelGGL((k_l2_tile<true, 1>), tile_grid(cols), dim3(64), 0, s, t);
-            else hipLaunchKernelGGL((k_l2_tile<false, 1>), tile_grid(cols), dim3(64), 0, s, t);
-        } else {
-            if (filter) hipLaunchKernelGGL((k_l2_tile<true, 4>), tile_grid(cols), dim3(256), 0, s, t);
-            else hipLaunchKernelGGL((k_l2_tile<false, 4>), tile_grid(cols), dim3(256), 0, s, t);
+        const size_t nct = (cols + TN - 1) / TN;
+        const dim3 grid((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles));
+        switch (geo * 2 + (filter ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((k_l2_tile<false, GeoSmall32>), grid, dim3(256), 0, s, t); break;
+            case 1: hipLaunchKernelGGL((k_l2_tile<true, GeoSmall32>), grid, dim3(256), 0, s, t); break;
+            case 2: hipLaunchKernelGGL((k_l2_tile<false, GeoSmall64>), grid, dim3(256), 0, s, t); break;
+            case 3: hipLaunchKernelGGL((k_l2_tile<true, GeoSmall64>), grid, dim3(256), 0, s, t); break;
+            case 4: hipLaunchKernelGGL((k_l2_tile<false, GeoBatch>), grid, dim3(256), 0, s, t); break;
+            default: hipLaunchKernelGGL((k_l2_tile<true, GeoBatch>), grid, dim3(256), 0, s, t); break;
         }
     };
     // bootstrap chunk through the slab
@@ -533,7 +567,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     size_t pos = boot;
     while (pos < f->nb) {
         size_t chunk = pos * w.cap / (4 * (size_t)k);
-        chunk = chunk / 128 * 128;
+        chunk = chunk / 256 * 256;
         if (chunk < 4096) chunk = 4096;
         if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
         if (chunk > f->nb - pos) chunk = f->nb - pos;
