@@ -90,13 +90,20 @@ using GeoSmall32 = TileGeo<32, 256, 1, 4>;
 // A ROWS-row x 32-k slab is staged in two steps so that the global loads of slab s+1 are in flight while the
 // matrix pipe works on slab s: fetch (global -> registers: thread t holds row t/KQ + ROWS_PER_IT*it, k = (t%KQ)*4 .. +3)
 // and commit (registers -> LDS, transposed to lds[k][row]).
-template <int IT, int ROWS_PER_IT>
+// FAST (d a multiple of the slab depth): no k bounds, and rows past the end re-read the last valid row instead of
+// being predicated off -- their products land in accumulator rows / columns the epilogue never emits.
+template <bool FAST, int IT, int ROWS_PER_IT>
 __device__ __forceinline__ void slab_fetch(float4 (&v)[IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int row = tid / KQ + ROWS_PER_IT * it;
         const uint32_t k = k0 + (tid % KQ) * 4;
+        if constexpr (FAST) {
+            const size_t rr = (size_t)row < rows_valid ? (size_t)row : rows_valid - 1;
+            v[it] = *reinterpret_cast<const float4 *>(src + (row0 + rr) * (size_t)d + k);
+            continue;
+        }
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((size_t)row < rows_valid) {
             const float *p = src + (row0 + row) * (size_t)d + k;
@@ -124,7 +131,7 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
     }
 }
 
-template <bool FILTER, class GEO>
+template <bool FILTER, class GEO, bool FAST>
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
     __shared__ float sA[TK * LDA];
@@ -150,29 +157,39 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     float4 ra[GEO::ITA], rb[GEO::ITB];
-    slab_fetch<GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
-    slab_fetch<GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
+    slab_fetch<FAST, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch<FAST, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
     for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
         __syncthreads();                               // the previous slab's fragment reads are done
         slab_commit<GEO::ITA, RPI, LDA>(sA, ra, tid);
         slab_commit<GEO::ITB, RPI, LDB>(sB, rb, tid);
         __syncthreads();
         if (k0 + TK < p.d) {                           // next slab's loads fly under this slab's MFMAs
-            slab_fetch<GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
-            slab_fetch<GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
+            slab_fetch<FAST, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
+            slab_fetch<FAST, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
         }
+        // operand fragments of k-step s+1 are read from LDS while the MFMAs of step s run
+        float a[2][MI], b[2][NJ];
+        const float *fa = sA + (lane >> 5) * LDA + wm + (lane & 31), *fb = sB + (lane >> 5) * LDB + wn + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = fa[32 * i];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) b[0][jj] = fb[32 * jj];
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 2) {
-            const int k = ks + (lane >> 5);
-            float a[MI], b[NJ];
+            const int cur = (ks >> 1) & 1, nxt = cur ^ 1;
+            if (ks + 2 < TK) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = sA[k * LDA + wm + 32 * i + (lane & 31)];
+                for (int i = 0; i < MI; ++i) a[nxt][i] = fa[(ks + 2) * LDA + 32 * i];
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) b[jj] = sB[k * LDB + wn + 32 * jj + (lane & 31)];
+                for (int jj = 0; jj < NJ; ++jj) b[nxt][jj] = fb[(ks + 2) * LDB + 32 * jj];
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads ahead of the MFMAs they overlap with
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
@@ -547,14 +564,18 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
         const dim3 grid((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles));
+        const bool fast = f->d % TK == 0;
+#define PF_TILE(FILTER, GEO) do { if (fast) hipLaunchKernelGGL((k_l2_tile<FILTER, GEO, true>), grid, dim3(256), 0, s, t); \
+                                  else hipLaunchKernelGGL((k_l2_tile<FILTER, GEO, false>), grid, dim3(256), 0, s, t); } while (0)
         switch (geo * 2 + (filter ? 1 : 0)) {
-            case 0: hipLaunchKernelGGL((k_l2_tile<false, GeoSmall32>), grid, dim3(256), 0, s, t); break;
-            case 1: hipLaunchKernelGGL((k_l2_tile<true, GeoSmall32>), grid, dim3(256), 0, s, t); break;
-            case 2: hipLaunchKernelGGL((k_l2_tile<false, GeoSmall64>), grid, dim3(256), 0, s, t); break;
-            case 3: hipLaunchKernelGGL((k_l2_tile<true, GeoSmall64>), grid, dim3(256), 0, s, t); break;
-            case 4: hipLaunchKernelGGL((k_l2_tile<false, GeoBatch>), grid, dim3(256), 0, s, t); break;
-            default: hipLaunchKernelGGL((k_l2_tile<true, GeoBatch>), grid, dim3(256), 0, s, t); break;
+            case 0: PF_TILE(false, GeoSmall32); break;
+            case 1: PF_TILE(true, GeoSmall32); break;
+            case 2: PF_TILE(false, GeoSmall64); break;
+            case 3: PF_TILE(true, GeoSmall64); break;
+            case 4: PF_TILE(false, GeoBatch); break;
+            default: PF_TILE(true, GeoBatch); break;
         }
+#undef PF_TILE
     };
     // bootstrap chunk through the slab
     const size_t boot = f->nb < w.boot ? f->nb : w.boot;
