@@ -32,7 +32,7 @@
 namespace pf {
 
 #ifndef PF_TK
-#define PF_TK 32
+#define PF_TK 16
 #endif
 constexpr int TK = PF_TK;                         // K slab depth of the distance tiles
 constexpr int KQ = TK / 4;                        // lanes covering one row of a slab (16 B each)
@@ -79,9 +79,9 @@ struct TileGeo {
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int MI = TM / (32 * WM), NJ = TN / (32 * WN);   // MFMA blocks per wave
     static constexpr int ROWS_PER_IT = THREADS / KQ;
-    static constexpr int ITA = TM / ROWS_PER_IT, ITB = TN / ROWS_PER_IT;   // fetch/commit iterations per thread
+    static constexpr int ITA = (TM + ROWS_PER_IT - 1) / ROWS_PER_IT, ITB = TN / ROWS_PER_IT;   // fetch/commit iterations per thread
     static constexpr int LDA = TM + 1, LDB = TN + 1;                 // k-major LDS rows padded by one float
-    static_assert(THREADS == 256 && ITA >= 1 && ITB >= 1 && MI >= 1 && NJ >= 1, "unsupported tile geometry");
+    static_assert(THREADS == 256 && TN % ROWS_PER_IT == 0 && (TM % ROWS_PER_IT == 0 || TM < ROWS_PER_IT) && MI >= 1 && NJ >= 1, "unsupported tile geometry");
 };
 using GeoBatch = TileGeo<128, 128, 2, 2>;
 using GeoSmall64 = TileGeo<64, 256, 1, 4>;
@@ -92,13 +92,14 @@ using GeoSmall32 = TileGeo<32, 256, 1, 4>;
 // and commit (registers -> LDS, transposed to lds[k][row]).
 // FAST (d a multiple of the slab depth): no k bounds, and rows past the end re-read the last valid row instead of
 // being predicated off -- their products land in accumulator rows / columns the epilogue never emits.
-template <bool FAST, int IT, int ROWS_PER_IT>
+template <bool FAST, int ROWS, int IT, int ROWS_PER_IT>
 __device__ __forceinline__ void slab_fetch(float4 (&v)[IT], const float *__restrict__ src, size_t row0, size_t rows_valid,
                                            uint32_t d, uint32_t k0, int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int row = tid / KQ + ROWS_PER_IT * it;
         const uint32_t k = k0 + (tid % KQ) * 4;
+        if (ROWS < ROWS_PER_IT && row >= ROWS) break;            // operand narrower than one sweep of the workgroup
         if constexpr (FAST) {
             const size_t rr = (size_t)row < rows_valid ? (size_t)row : rows_valid - 1;
             v[it] = *reinterpret_cast<const float4 *>(src + (row0 + rr) * (size_t)d + k);
@@ -118,11 +119,12 @@ __device__ __forceinline__ void slab_fetch(float4 (&v)[IT], const float *__restr
     }
 }
 
-template <int IT, int ROWS_PER_IT, int LD>
+template <int ROWS, int IT, int ROWS_PER_IT, int LD>
 __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int row = tid / KQ + ROWS_PER_IT * it;
+        if (ROWS < ROWS_PER_IT && row >= ROWS) break;
         const int kk = (tid % KQ) * 4;
         lds[(kk + 0) * LD + row] = v[it].x;
         lds[(kk + 1) * LD + row] = v[it].y;
@@ -134,8 +136,9 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
 template <bool FILTER, class GEO, bool FAST>
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
-    __shared__ float sA[TK * LDA];
-    __shared__ float sB[TK * LDB];
+    __shared__ float sAb[2][TK * LDA];            // two k-slabs in flight: one feeds the MFMAs, the next is being filled
+    __shared__ float sBb[2][TK * LDB];
+    float *const sA = sAb[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
     // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the base tile is
@@ -157,20 +160,29 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     float4 ra[GEO::ITA], rb[GEO::ITB];
-    slab_fetch<FAST, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
-    slab_fetch<FAST, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
-    for (uint32_t k0 = 0; k0 < p.d; k0 += TK) {
-        __syncthreads();                               // the previous slab's fragment reads are done
-        slab_commit<GEO::ITA, RPI, LDA>(sA, ra, tid);
-        slab_commit<GEO::ITB, RPI, LDB>(sB, rb, tid);
-        __syncthreads();
-        if (k0 + TK < p.d) {                           // next slab's loads fly under this slab's MFMAs
-            slab_fetch<FAST, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + TK, tid);
-            slab_fetch<FAST, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + TK, tid);
+    slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
+    slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[0], ra, tid);
+    slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[0], rb, tid);
+    if (TK < p.d) {
+        slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, TK, tid);
+        slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, TK, tid);
+    }
+    __syncthreads();
+    // slab s feeds the matrix pipe from buffer s&1 while slab s+1 (in registers since the previous iteration) is
+    // committed to the other buffer and slab s+2 is requested from memory: one barrier per slab
+    for (uint32_t k0 = 0, cur = 0; k0 < p.d; k0 += TK, cur ^= 1) {
+        if (k0 + TK < p.d) {
+            slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[cur ^ 1], ra, tid);
+            slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[cur ^ 1], rb, tid);
+            if (k0 + 2 * TK < p.d) {
+                slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + 2 * TK, tid);
+                slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + 2 * TK, tid);
+            }
         }
         // operand fragments of k-step s+1 are read from LDS while the MFMAs of step s run
         float a[2][MI], b[2][NJ];
-        const float *fa = sA + (lane >> 5) * LDA + wm + (lane & 31), *fb = sB + (lane >> 5) * LDB + wn + (lane & 31);
+        const float *fa = sAb[cur] + (lane >> 5) * LDA + wm + (lane & 31), *fb = sBb[cur] + (lane >> 5) * LDB + wn + (lane & 31);
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[0][i] = fa[32 * i];
 #pragma unroll
@@ -191,6 +203,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
     }
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     if constexpr (FILTER) {
