@@ -36,7 +36,11 @@ namespace pf {
 #endif
 constexpr int TK = PF_TK;                         // K slab depth of the distance tiles
 constexpr int KQ = TK / 4;                        // lanes covering one row of a slab (16 B each)
-constexpr uint32_t SEL_CAP = 2048;                // reservoir capacity (keys); k <= SEL_CAP/2
+#ifndef PF_SEL_CAP
+#define PF_SEL_CAP 2048
+#endif
+constexpr uint32_t SEL_CAP = PF_SEL_CAP;          // reservoir capacity (keys)
+constexpr uint32_t K_MAX = 1024;                  // largest k
 constexpr uint32_t SEL_THREADS = 256;
 constexpr uint64_t KEY_INF = 0x7F800000FFFFFFFFull;   // (+inf, id 2^32-1): sorts after every real key
 
@@ -290,9 +294,14 @@ struct SelArgs {
 
 // in-LDS bitonic sort of the first n keys (n a power of two <= SEL_CAP; the rest must already be KEY_INF), ascending
 __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n = SEL_CAP) {
+    // Pair t of a step touches elements 2t - (t & (stride-1)) and + stride.  A wave always owns the same 64 consecutive
+    // pairs, which for stride <= 64 live in one aligned block of 128 elements: such steps only exchange data inside
+    // the wave (LDS operations of a wave execute in order) and need no workgroup barrier.
+    __syncthreads();
     for (uint32_t size = 2; size <= n; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (stride > 64 || (stride == 64 && size > 128)) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
             for (uint32_t t = tid; t < n / 2; t += SEL_THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));
                 const uint32_t hi = lo + stride;
@@ -382,8 +391,8 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
         });
     }
     // sort, keep k, carry or emit (a merge usually holds far fewer than SEL_CAP keys: sort only what is there)
-    uint32_t n_sort = SEL_CAP;
-    if (merge) { n_sort = 64; while (n_sort < c0 + nc) n_sort <<= 1; }
+    uint32_t n_sort = 64;
+    while (n_sort < cnt) n_sort <<= 1;                          // cnt is stable: the scan ends with a barrier
     bitonic_sort(keys, tid, n_sort);
     const uint32_t total = cnt < k ? cnt : k;
     if (p.last) {
@@ -460,7 +469,10 @@ struct pf_flat {
 namespace {
 
 constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
-constexpr size_t MAX_CHUNK = 262144;       // largest streaming chunk
+#ifndef PF_MAX_CHUNK
+#define PF_MAX_CHUNK 262144
+#endif
+constexpr size_t MAX_CHUNK = PF_MAX_CHUNK; // largest streaming chunk (bounds the cost of one overflow rescan)
 
 struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, total; };
 
@@ -547,7 +559,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
     if (nq == 0) return PF_OK;
     if (!xq || !D || !I) return fail(PF_ERR_INVALID_ARG, "null argument");
-    if (k == 0 || k > SEL_CAP / 2) return fail(PF_ERR_UNSUPPORTED, "k must be in [1, 1024]");
+    if (k == 0 || k > K_MAX) return fail(PF_ERR_UNSUPPORTED, "k must be in [1, 1024]");
     if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
     hipStream_t s = as_stream(stream);
