@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         if (tid < TM) {
             const bool ok = q0 + tid < p.nq;
             sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
-            sA[TM + tid] = ok ? p.tau[q0 + tid] : -1.f;             // -1: nothing passes (distances are >= 0)
+            sA[TM + tid] = ok ? p.tau[q0 + tid] : -INFINITY;        // rows past nq: nothing passes
         }
         __syncthreads();
     }
@@ -242,8 +242,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
                     dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                    dist[jj] = dist[jj] < 0.f ? 0.f : dist[jj];
-                    pass[jj] = col_ok[jj] && dist[jj] <= tv;
+                    pass[jj] = col_ok[jj] && dist[jj] <= tv;        // tau >= 0: same verdict before and after the clamp at 0
                     const uint64_t m = __ballot(pass[jj]);
                     any |= m != 0;
                     hm[jj] = (uint32_t)(m >> (lane & 32));
@@ -260,7 +259,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
                 for (int jj = 0; jj < NJ; ++jj) {
                     if (pass[jj]) {
                         const uint32_t pos = base + __popc(hm[jj] & below);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj], (uint32_t)(p.nb_first + col[jj]));
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj] < 0.f ? 0.f : dist[jj], (uint32_t)(p.nb_first + col[jj]));
                     }
                     base += __popc(hm[jj]);
                 }
@@ -464,6 +463,7 @@ struct pf_flat {
     // workspace (grown outside graph capture)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    size_t wg_slots = 1024;   // workgroups of the tile kernel resident on the device at once (CUs x occupancy)
 };
 
 namespace {
@@ -538,6 +538,14 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
+    {
+        hipDeviceProp_t prop;
+        int occ = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_l2_tile<true, GeoBatch, true>, 256, 0) == hipSuccess && occ > 0)
+            f->wg_slots = (size_t)prop.multiProcessorCount * (size_t)occ;
+        (void)hipGetLastError();
+    }
     *out = f;
     return PF_OK;
 }
@@ -616,6 +624,9 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         chunk = chunk / 256 * 256;
         if (chunk < 4096) chunk = 4096;
         if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
+        // whole rounds of resident workgroups: a chunk that fills the device 1.2 times takes as long as one that fills it twice
+        const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
+        if (chunk > round_cols) chunk = chunk / round_cols * round_cols;
         if (chunk > f->nb - pos) chunk = f->nb - pos;
         t.nb_first = pos; t.nb_count = chunk;
         launch_tile(true, chunk);
