@@ -65,10 +65,13 @@ pf_status pf_stream_synchronize(int device, pf_stream stream);
  * every modulus prime, < 2^61, = 1 mod 2N.  Blocking (synchronises the upload). */
 pf_status pf_ctx_create(pf_ctx **ctx, int device, uint32_t N, uint32_t L, const uint64_t *moduli_host);
 pf_status pf_ctx_destroy(pf_ctx *ctx);
-/* arith_path_out[l]: 0 = exact-FP64 butterflies, 1 = 64-bit Shoup/Harvey butterflies.  Any out pointer may be NULL. */
+/* arith_path_out[l]: 0 = exact-FP64 butterflies (every q < 2^45), 2 = 64-bit Shoup butterflies with the range
+ * corrections hoisted out (every q < 2^56), 1 = 64-bit Shoup/Harvey butterflies (any q < 2^61).  One family per
+ * context.  Any out pointer may be NULL. */
 pf_status pf_ctx_info(const pf_ctx *ctx, uint32_t *N, uint32_t *L, uint64_t *moduli_out_host,
                       uint64_t *psi_out_host, int32_t *arith_path_out_host);
-/* Testing hook: force every limb onto the 64-bit integer path (1) or restore automatic choice (0). */
+/* Testing hook: 0 = automatic choice, 1 = 64-bit integer butterflies (family 2 where the moduli allow, else 1),
+ * 2 = the general Harvey butterflies (family 1). */
 pf_status pf_ctx_force_u64(pf_ctx *ctx, int on);
 
 /* ---- polynomial arithmetic -------------------------------------------------------------------- */

@@ -67,8 +67,9 @@ class RnsContext:
         check(lib.pf_ctx_info(self._h, None, None, None, psi, path), "pf_ctx_info")
         return {"psi": list(psi), "arith_path": list(path)}
 
-    def force_u64(self, on=True):
-        check(lib.pf_ctx_force_u64(self._h, int(bool(on))), "pf_ctx_force_u64")
+    def force_u64(self, mode=1):
+        """0 automatic, 1 64-bit integer butterflies (lazy family where every q < 2^56), 2 general Harvey butterflies."""
+        check(lib.pf_ctx_force_u64(self._h, int(mode)), "pf_ctx_force_u64")
 
     def _count(self, t):
         if t.numel() % self.N:

@@ -84,6 +84,13 @@ PF_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 #endif
 }
 
+// floor(a*b / 2^64) - e with e in {0, 1, 2}: the three partial products that reach the high word, without the
+// low x low product and without the carries of the cross terms (three 32-bit multiplies instead of four plus carries)
+PF_HD uint64_t mulhi64_under(uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    return (uint64_t)a1 * b1 + (uint32_t)(((uint64_t)a1 * b0) >> 32) + (uint32_t)(((uint64_t)a0 * b1) >> 32);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Geometry
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +229,7 @@ struct ArithF64 {
         for (int i = 0; i < NB; ++i) v[i] = __builtin_fma(-c[i], q, v[i]);
     }
     PF_HD void fwd_combine(V &x, V &y, V m) const { y = x - m; x = x + m; }
-    PF_HD void inv_split(V &x, V y, V &d) const { d = x - y; x = x + y; }
+    template <int J> PF_HD void inv_split(V &x, V y, V &d) const { d = x - y; x = x + y; }
     template <int NB> PF_HD void pass_reduce_n(V (&v)[NB]) const { recentre_n<NB>(v); }
     template <int NB> PF_HD void for_dyadic_n(V (&)[NB]) const {}
     PF_HD V add(V a, V b) const { return a + b; }
@@ -236,7 +243,28 @@ struct ArithF64 {
 };
 
 // ArithU64: SEAL's lazy Harvey butterflies.  forward values live in [0,4q), inverse values in [0,2q).
-struct ArithU64 {
+// ArithU64T<false> ("ArithU64"): Harvey's lazy butterflies as SEAL runs them -- values in [0, 4q), one conditional
+// subtraction of 2q per butterfly, Shoup products in [0, 2q); any q < 2^61.
+// ArithU64T<true> ("ArithU64L", q < 2^56, LOGN <= 15, at most 6 stages per pass): the 64-bit word has 8 spare bits,
+// so the range corrections leave the butterflies.
+//   * product: m = y*w - c'*q with c' = mulhi64_under(y, w') >= floor(y*w'/2^64) - 2.  Shoup's bound
+//     y*w - floor(y*w'/2^64)*q < q*(1 + y/2^64) < 2q holds for EVERY y < 2^64, hence 0 <= m < 4q.
+//   * forward: x' = x + m, y' = x + 4q - m: the bound grows by 4q per stage, (1 + 4*15) q = 61 q < 2^62 at the end;
+//     canon_n brings a value back with one exact Shoup product by 1 (ratio1 = floor(2^64/q)).  The dyadic Barrett
+//     reduction takes the lazy operand as it is (a*b < 61 q^2 < 2^128).
+//   * inverse: stage j of a pass (j = 0 first) sees values below 4q*2^j: s = x + y < 4q*2^(j+1),
+//     d = x + 4q*2^j - y < 4q*2^(j+1), the product brings d back below 4q; 4q*2^6 = 2^8 q < 2^64.  After a pass the
+//     registers that ended as sums are reduced to [0, 2q) (pass_reduce_n, again a Shoup product by 1), so every
+//     pass starts below 4q.  The last layer multiplies both halves; canon_small takes [0, 4q).
+#if !defined(__HIPCC__) && defined(PF_RANGE_CHECK)
+inline unsigned long long pf_range_violations = 0;          // host simulator only: a 64-bit sum that wrapped, a bound that failed
+#define PF_RANGE_ASSERT(c) do { if (!(c)) ++pf_range_violations; } while (0)
+#else
+#define PF_RANGE_ASSERT(c) do { } while (0)
+#endif
+
+template <bool LAZY>
+struct ArithU64T {
     using V = uint64_t;
     using Tw = TwU64;
     using TwR = TwU64;
@@ -250,21 +278,39 @@ struct ArithU64 {
     PF_HD TwR resolve(Tw t) const { return t; }
     static PF_HD TwR with_quotient(Tw t, double) { return t; }
     PF_HD V guard(V v) const { return v >= two_q ? v - two_q : v; }
+    PF_HD V shoup_one(V v) const { return v - mulhi64(v, ratio1) * q; }                // any v < 2^64 -> [0, 2q)
     template <int NB>
     PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {
         uint64_t hi[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) hi[i] = mulhi64(y[i], t[i].wq);
+        for (int i = 0; i < NB; ++i) hi[i] = LAZY ? mulhi64_under(y[i], t[i].wq) : mulhi64(y[i], t[i].wq);
         PF_SCHED_FENCE();
 #pragma unroll
-        for (int i = 0; i < NB; ++i) y[i] = y[i] * t[i].w - hi[i] * q;                 // [0,2q)
+        for (int i = 0; i < NB; ++i) y[i] = y[i] * t[i].w - hi[i] * q;                 // [0,2q), LAZY: [0,4q)
     }
-    PF_HD void fwd_combine(V &x, V &y, V m) const { const V u = guard(x); x = u + m; y = u + two_q - m; }
-    PF_HD void inv_split(V &x, V y, V &d) const { d = x + two_q - y; x = guard(x + y); }
-    template <int NB> PF_HD void pass_reduce_n(V (&)[NB]) const {}
-    // Barrett 128->64 (SEAL dyadic_product_coeffmod); operands must be canonical
+    PF_HD void fwd_combine(V &x, V &y, V m) const {
+        if constexpr (LAZY) {
+            PF_RANGE_ASSERT(m < (two_q << 1) && x <= ~0ull - (two_q << 1));
+            y = x + (two_q << 1) - m; x = x + m;
+        }
+        else { const V u = guard(x); x = u + m; y = u + two_q - m; }
+    }
+    template <int J> PF_HD void inv_split(V &x, V y, V &d) const {
+        if constexpr (LAZY) {
+            PF_RANGE_ASSERT(x < (two_q << (J + 1)) && y < (two_q << (J + 1)) && (two_q << (J + 1)) <= (1ull << 63));
+            d = x + (two_q << (J + 1)) - y; x = x + y;
+        }
+        else { d = x + two_q - y; x = guard(x + y); }
+    }
+    template <int NB> PF_HD void pass_reduce_n(V (&v)[NB]) const {
+        if constexpr (LAZY) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[i] = shoup_one(v[i]);
+        }
+    }
+    // Barrett 128->64 (SEAL barrett_reduce_128): the quotient estimate is floor(z/q) or one less for any z < 2^128,
+    // so one conditional subtraction canonicalises; the operands themselves need not be canonical
     PF_HD V dyadic(V a, V b) const { return barrett128(a * b, mulhi64(a, b)); }
-    // (z1:z0) mod q for z < 2^128 / ... (SEAL barrett_reduce_128): result canonical
     PF_HD V barrett128(uint64_t z0, uint64_t z1) const {
         const uint64_t carry = mulhi64(z0, ratio0);
         const uint64_t t2lo = z0 * ratio1, t2hi = mulhi64(z0, ratio1);
@@ -283,14 +329,21 @@ struct ArithU64 {
         for (int i = 0; i < NB; ++i) a[i] = dyadic(a[i], b[i]);
     }
     PF_HD V add(V a, V b) const { return a + b; }
-    template <int NB> PF_HD void canon_n(V (&v)[NB]) const {                          // from [0,4q)
+    template <int NB> PF_HD void canon_n(V (&v)[NB]) const {                          // from the forward transform's range
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { V r = guard(v[i]); v[i] = r >= q ? r - q : r; }
+        for (int i = 0; i < NB; ++i) { V r = LAZY ? shoup_one(v[i]) : guard(v[i]); v[i] = r >= q ? r - q : r; }
     }
-    template <int NB> PF_HD void for_dyadic_n(V (&v)[NB]) const { canon_n<NB>(v); }
-    PF_HD V canon_small(V v) const { return v >= q ? v - q : v; }                    // from [0,2q)
+    template <int NB> PF_HD void for_dyadic_n(V (&)[NB]) const {}
+    PF_HD V canon_small(V v) const {                                                  // from the inverse transform's range
+        PF_RANGE_ASSERT(v < (LAZY ? two_q << 1 : two_q));
+        if constexpr (LAZY) v = guard(v);
+        return v >= q ? v - q : v;
+    }
     PF_HD V canon_sum(V v) const { V r = v >= two_q ? v - two_q : v; return r >= q ? r - q : r; }   // from [0,3q)
 };
+using ArithU64 = ArithU64T<false>;
+using ArithU64L = ArithU64T<true>;
+inline bool u64_lazy_ok(uint64_t q, int logn) { return logn <= 15 && q < (1ull << 56); }
 
 // ------------------------------------------------------------------------------------------------
 // Passes
@@ -396,7 +449,7 @@ PF_HD void inv_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, P
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
-                ar.inv_split(r[k0], r[k0 | (1 << KB)], ds[i]);
+                ar.template inv_split<KB>(r[k0], r[k0 | (1 << KB)], ds[i]);
                 ts[i] = T.get(ar, KB, b >> KB);
             }
             ar.template mul_tw_n<NBATCH>(ds, ts);
@@ -427,7 +480,7 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
             for (int i = 0; i < NBATCH / 2; ++i) {
                 const int j = bb + i;
                 vs[2 * i] = r[j];
-                ar.inv_split(vs[2 * i], r[j + G::R / 2], vs[2 * i + 1]);
+                ar.template inv_split<G::nl(0) - 1>(vs[2 * i], r[j + G::R / 2], vs[2 * i + 1]);
                 ts[2 * i] = tn; ts[2 * i + 1] = t;
             }
             ar.template mul_tw_n<NBATCH>(vs, ts);

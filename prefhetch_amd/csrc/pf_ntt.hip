@@ -22,7 +22,9 @@ using namespace pf;
 struct pf_ctx {
     int device = 0;
     uint32_t N = 0, L = 0, logn = 0;
-    bool all_f64 = false, force_u64 = false;
+    bool all_f64 = false, all_lazy64 = false;   // every modulus admits the exact-FP64 / the lazy 64-bit butterflies
+    int force_u64 = 0;                           // 0 automatic, 1 64-bit integer butterflies, 2 Harvey butterflies (any q < 2^61)
+    int arith() const { return (all_f64 && !force_u64) ? 0 : (all_lazy64 && force_u64 != 2) ? 2 : 1; }
     int num_cus = 256;
     std::vector<LimbTables> tabs;
     LimbDev *d_limbs = nullptr;
@@ -53,7 +55,7 @@ pf_status run_ntt_like(pf_ctx *c, int op, int flags, const NttArgs &a, size_t n,
     if (n == 0) return PF_OK;
     if (n > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
     PF_GUARD(c->device);
-    const int arith = (c->all_f64 && !c->force_u64) ? 0 : 1;
+    const int arith = c->arith();
     return dispatch_logn(c, arith, op, flags, a, n, as_stream(stream));
 }
 
@@ -158,11 +160,12 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
     c->tabs.resize(L);
-    c->all_f64 = true;
+    c->all_f64 = c->all_lazy64 = true;
     for (uint32_t l = 0; l < L; ++l) {
         std::string err;
         if (!build_limb_tables(N, moduli[l], c->tabs[l], err)) { delete c; return fail(PF_ERR_INVALID_ARG, "modulus " + std::to_string(l) + ": " + err); }
         c->all_f64 = c->all_f64 && c->tabs[l].f64_ok;
+        c->all_lazy64 = c->all_lazy64 && u64_lazy_ok(moduli[l], (int)c->logn);
     }
     std::vector<LimbDev> host(L);
     static_assert(sizeof(TwU64) == 16 && sizeof(TwF64) == 8, "table entry sizes");
@@ -215,14 +218,15 @@ pf_status pf_ctx_info(const pf_ctx *c, uint32_t *N, uint32_t *L, uint64_t *modul
     for (uint32_t l = 0; l < c->L; ++l) {
         if (moduli) moduli[l] = c->tabs[l].q;
         if (psi) psi[l] = c->tabs[l].psi;
-        if (path) path[l] = (c->all_f64 && !c->force_u64) ? 0 : 1;
+        if (path) path[l] = c->arith();
     }
     return PF_OK;
 }
 
 pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
     if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
-    c->force_u64 = on != 0;
+    if (on < 0 || on > 2) return fail(PF_ERR_INVALID_ARG, "pf_ctx_force_u64: 0, 1 or 2");
+    c->force_u64 = on;
     return PF_OK;
 }
 
@@ -273,7 +277,7 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
         c->ks_ws_bytes = need;
     }
     uint64_t *x = static_cast<uint64_t *>(c->ks_ws), *acc = x + x_words;
-    const int arith = (c->all_f64 && !c->force_u64) ? 0 : 1;
+    const int arith = c->arith();
     const uint32_t chunk_log = c->logn < 11 ? c->logn : 11;
     const size_t chunks = N >> chunk_log;
     for (size_t b0 = 0; b0 < B; b0 += sub) {

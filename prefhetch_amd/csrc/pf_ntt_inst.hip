@@ -27,6 +27,7 @@ void launch_family(int op, int flags, const NttArgs &a, unsigned nblocks, hipStr
 
 void PF_CAT(launch_logn_, PF_INST_LOGN)(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s) {
     if (arith == 0) launch_family<PF_INST_LOGN, ArithF64>(op, flags, a, grid, s);
+    else if (arith == 2) launch_family<PF_INST_LOGN, ArithU64L>(op, flags, a, grid, s);
     else launch_family<PF_INST_LOGN, ArithU64>(op, flags, a, grid, s);
 }
 

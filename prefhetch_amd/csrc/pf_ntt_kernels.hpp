@@ -37,8 +37,8 @@ template <> struct ArithOf<ArithF64> {
     static __device__ __forceinline__ const TwF64 *fwd(const void *t, const LimbDev &l) { return reinterpret_cast<const TwF64 *>(static_cast<const uint64_t *>(t) + l.fwd_f); }
     static __device__ __forceinline__ const TwF64 *inv(const void *t, const LimbDev &l) { return reinterpret_cast<const TwF64 *>(static_cast<const uint64_t *>(t) + l.inv_f); }
 };
-template <> struct ArithOf<ArithU64> {
-    static __device__ __forceinline__ ArithU64 make(const LimbDev &l) { return ArithU64{l.q, l.two_q, l.ratio0, l.ratio1}; }
+template <bool LAZY> struct ArithOf<ArithU64T<LAZY>> {
+    static __device__ __forceinline__ ArithU64T<LAZY> make(const LimbDev &l) { return ArithU64T<LAZY>{l.q, l.two_q, l.ratio0, l.ratio1}; }
     static __device__ __forceinline__ const TwU64 *fwd(const void *t, const LimbDev &l) { return reinterpret_cast<const TwU64 *>(static_cast<const uint64_t *>(t) + l.fwd_u); }
     static __device__ __forceinline__ const TwU64 *inv(const void *t, const LimbDev &l) { return reinterpret_cast<const TwU64 *>(static_cast<const uint64_t *>(t) + l.inv_u); }
 };
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_elementwise(EwArgs p) {
 
 
 namespace pf {
-// Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64;
+// Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64, 2 = ArithU64L;
 // op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`, 3 key-switch digit NTT.
 #define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
 PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14) PF_DECL_LAUNCH(15)

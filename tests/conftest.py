@@ -27,10 +27,11 @@ def sim_lib():
     src = os.path.join(ROOT, "tests", "cpp", "sim_ntt.cpp")
     deps = [src] + [os.path.join(ROOT, "prefhetch_amd", "csrc", f) for f in ("ntt_core.hpp", "tables.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-std=c++20", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", src, "-o", so])
+        subprocess.check_call(["g++", "-std=c++20", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-DPF_RANGE_CHECK", "-shared", "-fPIC", src, "-o", so])
     lib = C.CDLL(so)
     u64p = C.POINTER(C.c_uint64)
     lib.pf_sim_run.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+    lib.pf_sim_range_violations.restype = C.c_ulonglong
     lib.pf_sim_psi.restype = C.c_uint64
     lib.pf_sim_psi.argtypes = [C.c_int, C.c_uint64]
     return lib

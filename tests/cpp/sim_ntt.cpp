@@ -53,7 +53,7 @@ static void dispatch(int logn, int op, int flags, const A &ar, const typename A:
     }
 }
 
-// op: 0 fwd, 1 inv, 2 ctpt(flags).  arith: 0 f64, 1 u64.  One limb-polynomial per call.
+// op: 0 fwd, 1 inv, 2 ctpt(flags).  arith: 0 f64, 1 u64 (Harvey), 2 u64 lazy (q < 2^56).  One limb-polynomial per call.
 extern "C" int pf_sim_run(int logn, uint64_t q, int arith, int op, int flags, const uint64_t *src,
                           const uint64_t *pt, uint64_t *dst) {
     LimbTables t;
@@ -64,12 +64,19 @@ extern "C" int pf_sim_run(int logn, uint64_t q, int arith, int op, int flags, co
         if (!t.f64_ok) return -3;
         ArithF64 ar{(double)q, 1.0 / (double)q};
         dispatch<ArithF64>(logn, op, flags, ar, t.fwd_f.data(), t.inv_f.data(), src, pt, dst);
+    } else if (arith == 2) {
+        if (!u64_lazy_ok(q, logn)) return -3;
+        ArithU64L ar{q, 2 * q, t.ratio0, t.ratio1};
+        dispatch<ArithU64L>(logn, op, flags, ar, t.fwd_u.data(), t.inv_u.data(), src, pt, dst);
     } else {
         ArithU64 ar{q, 2 * q, t.ratio0, t.ratio1};
         dispatch<ArithU64>(logn, op, flags, ar, t.fwd_u.data(), t.inv_u.data(), src, pt, dst);
     }
     return 0;
 }
+
+// number of range-analysis violations seen so far by the 64-bit lazy butterflies (must stay 0)
+extern "C" unsigned long long pf_sim_range_violations() { return pf::pf_range_violations; }
 
 extern "C" uint64_t pf_sim_psi(int logn, uint64_t q) {
     LimbTables t; std::string err;

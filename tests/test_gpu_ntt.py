@@ -23,14 +23,20 @@ def pf():
     return prefhetch_amd
 
 
-def _ctx(pf, N, qs, force_u64=False):
+def _ctx(pf, N, qs, force_u64=0):
     c = pf.RnsContext(N, qs, _dev())
     if force_u64:
-        c.force_u64(True)
+        c.force_u64(int(force_u64))
     return c
 
 
-CONFIGS = [  # (N, moduli, force_u64)
+CONFIGS = [  # (N, moduli, force_u64: 0 automatic, 1 64-bit integer butterflies, 2 general Harvey butterflies)
+    (1024, oracle.BFV_DEFAULT[1024], 2),
+    (8192, oracle.BFV_DEFAULT[8192], 2),
+    (8192, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001], 2),
+    (16384, [0xFFFFFFFFFFC0001, 0x7FFFFFFFE90001], False),    # a 60-bit prime: general Harvey butterflies automatically
+    (32768, [0x1FFFFFFFFFE10001, 0xFFFFFFFFF70001], False),   # a 61-bit prime at N=32768
+    (32768, oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:], 2),
     (1024, oracle.BFV_DEFAULT[1024], False),
     (1024, oracle.BFV_DEFAULT[1024], True),
     (2048, oracle.BFV_DEFAULT[2048], False),              # 54-bit prime -> u64 path automatically
@@ -54,7 +60,8 @@ def test_ntt_roundtrip_and_parity(pf, N, qs, force):
     c = _ctx(pf, N, qs, force)
     info = c.info()
     assert info["psi"] == [o.psi(l) for l in range(L)]
-    expect_path = 1 if (force or any(q >= 1 << 45 for q in qs)) else 0
+    wide = force == 2 or any(q >= 1 << 56 for q in qs)
+    expect_path = (1 if wide else 2) if (force or any(q >= 1 << (44 if N == 32768 else 45) for q in qs)) else 0
     assert info["arith_path"] == [expect_path] * L
     polys = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 2, 3, 4, 0, 0)])  # [7][L][N]
     d = pf.to_device_u64(polys, _dev())
@@ -116,7 +123,7 @@ def test_golden_vectors_on_gpu(pf, golden):
     for ci in (4, 5):                                      # the N = 1024 fixtures (smaller N is below the kernel range)
         g = lambda k: golden[f"c{ci}_{k}"]
         q = int(g("q"))
-        for force in (False, True):
+        for force in (0, 1, 2):
             c = _ctx(pf, 1024, [q], force)
             d = pf.to_device_u64(np.stack([g("a"), g("b")]), _dev())
             c.ntt_forward_(d)

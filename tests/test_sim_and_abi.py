@@ -16,7 +16,10 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
-SIM_CASES = [  # (logn, q, arithmetic) 0 = exact-FP64, 1 = u64 Shoup
+SIM_CASES = [  # (logn, q, arithmetic) 0 = exact-FP64, 1 = u64 Harvey/Shoup, 2 = u64 lazy (q < 2^56)
+    (10, 0x7E00001, 2), (12, 0x1FFFFE0001, 2), (13, 0xFFFFFFFC001, 2), (11, 0x3FFFFFFF000001, 2),
+    (13, 0x7FFFFFFFE90001, 2), (14, 0x7FFFFFFFE90001, 2), (15, 0x7FFFFFFFE90001, 2), (15, 0xFFFFFFFFF70001, 2),
+    (14, 0xFFFFFFFFFFC0001, 1), (15, 0x1FFFFFFFFFE10001, 1),     # 60- and 61-bit primes: Harvey butterflies only
     (10, 0x7E00001, 0), (10, 0x7E00001, 1),
     (12, 0xFFFFEE001, 0), (12, 0x1FFFFE0001, 1),
     (13, 0x7FFFFFD8001, 0), (13, 0xFFFFFEBC001, 0), (13, 0xFFFFFFFC001, 1),
@@ -51,6 +54,7 @@ def test_device_core_on_host_simulator(sim_lib, logn, q, arith):
                               acc=np.stack([acc0, acc0]).reshape(1, 2, 1, N)).reshape(2, N)[0]
             assert sim_lib.pf_sim_run(logn, q, arith, 2, flags, _p(src), _p(bn), _p(dst)) == 0
             assert (dst == exp).all(), (flags, kind)
+    assert sim_lib.pf_sim_range_violations() == 0           # the lazy butterflies stayed inside their analysed bounds
 
 
 def test_simulator_golden_n1024(sim_lib, golden):
@@ -70,6 +74,11 @@ def test_simulator_golden_n1024(sim_lib, golden):
 def test_fp64_path_rejected_for_wide_primes(sim_lib):
     a = np.zeros(8192, dtype=np.uint64)
     assert sim_lib.pf_sim_run(13, 0x7FFFFFFFE90001, 0, 0, 0, _p(a), _p(a), _p(a)) == -3
+
+
+def test_lazy_u64_path_rejected_for_wide_primes(sim_lib):
+    a = np.zeros(16384, dtype=np.uint64)
+    assert sim_lib.pf_sim_run(14, 0xFFFFFFFFFFC0001, 2, 0, 0, _p(a), _p(a), _p(a)) == -3
 
 
 def test_library_loads_and_exports_header_symbols():
