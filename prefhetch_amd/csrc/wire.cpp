@@ -1,0 +1,336 @@
+// wire.cpp -- JSON bodies and route handlers of the PreFHEtch server (include/server/wire.h), restating
+// /root/reference/src/server/controllers/Query.cc:9-127 without Drogon or nlohmann.
+#include "../../include/server/wire.h"
+
+#include <array>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+namespace wire {
+
+// ---- reader ------------------------------------------------------------------------------------------
+namespace {
+
+struct Reader {
+    const char *p, *end, *begin;
+    [[noreturn]] void fail(const char *what) const {
+        throw ParseError(std::string("JSON parse error at byte ") + std::to_string(p - begin) + ": " + what);
+    }
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool lit(const char *word) {
+        const size_t n = std::strlen(word);
+        if ((size_t)(end - p) < n || std::memcmp(p, word, n) != 0) return false;
+        p += n;
+        return true;
+    }
+    std::string string() {
+        std::string out;
+        ++p;                                              // opening quote
+        for (;;) {
+            if (p >= end) fail("unterminated string");
+            const char c = *p++;
+            if (c == '"') return out;
+            if ((unsigned char)c < 0x20) fail("control character in string");
+            if (c != '\\') { out.push_back(c); continue; }
+            if (p >= end) fail("unterminated escape");
+            const char e = *p++;
+            switch (e) {
+                case '"': out.push_back('"'); break;
+                case '\\': out.push_back('\\'); break;
+                case '/': out.push_back('/'); break;
+                case 'b': out.push_back('\b'); break;
+                case 'f': out.push_back('\f'); break;
+                case 'n': out.push_back('\n'); break;
+                case 'r': out.push_back('\r'); break;
+                case 't': out.push_back('\t'); break;
+                case 'u': {
+                    if (end - p < 4) fail("short \\u escape");
+                    unsigned cp = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const char h = *p++;
+                        cp <<= 4;
+                        if (h >= '0' && h <= '9') cp |= (unsigned)(h - '0');
+                        else if (h >= 'a' && h <= 'f') cp |= (unsigned)(h - 'a' + 10);
+                        else if (h >= 'A' && h <= 'F') cp |= (unsigned)(h - 'A' + 10);
+                        else fail("bad \\u escape");
+                    }
+                    // keys of this protocol are ASCII; other code points are kept as UTF-8 (BMP only, no surrogate pairing)
+                    if (cp < 0x80) out.push_back((char)cp);
+                    else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                    else { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                    break;
+                }
+                default: fail("unknown escape");
+            }
+        }
+    }
+    Json number() {
+        const char *s = p;
+        bool integral = true;
+        if (p < end && *p == '-') ++p;
+        if (p >= end || *p < '0' || *p > '9') fail("digit expected");
+        if (*p == '0') ++p; else while (p < end && *p >= '0' && *p <= '9') ++p;
+        if (p < end && *p == '.') {
+            integral = false;
+            ++p;
+            if (p >= end || *p < '0' || *p > '9') fail("digit expected after the decimal point");
+            while (p < end && *p >= '0' && *p <= '9') ++p;
+        }
+        if (p < end && (*p == 'e' || *p == 'E')) {
+            integral = false;
+            ++p;
+            if (p < end && (*p == '+' || *p == '-')) ++p;
+            if (p >= end || *p < '0' || *p > '9') fail("digit expected in the exponent");
+            while (p < end && *p >= '0' && *p <= '9') ++p;
+        }
+        const std::string tok(s, p);
+        Json j;
+        if (integral) {
+            errno = 0;
+            char *e = nullptr;
+            const long long v = std::strtoll(tok.c_str(), &e, 10);
+            if (errno == 0 && e && *e == 0) { j.kind = Json::Int; j.i = v; j.f = (double)v; return j; }
+        }
+        j.kind = Json::Float;
+        j.f = std::strtod(tok.c_str(), nullptr);
+        return j;
+    }
+    Json value(int depth) {
+        if (depth > 64) fail("nesting too deep");
+        ws();
+        if (p >= end) fail("value expected");
+        Json j;
+        switch (*p) {
+            case '{': {
+                ++p;
+                j.kind = Json::Object;
+                ws();
+                if (p < end && *p == '}') { ++p; return j; }
+                for (;;) {
+                    ws();
+                    if (p >= end || *p != '"') fail("object key expected");
+                    std::string key = string();
+                    ws();
+                    if (p >= end || *p != ':') fail("':' expected");
+                    ++p;
+                    j.obj.emplace_back(std::move(key), value(depth + 1));
+                    ws();
+                    if (p < end && *p == ',') { ++p; continue; }
+                    if (p < end && *p == '}') { ++p; return j; }
+                    fail("',' or '}' expected");
+                }
+            }
+            case '[': {
+                ++p;
+                j.kind = Json::Array;
+                ws();
+                if (p < end && *p == ']') { ++p; return j; }
+                for (;;) {
+                    j.arr.push_back(value(depth + 1));
+                    ws();
+                    if (p < end && *p == ',') { ++p; continue; }
+                    if (p < end && *p == ']') { ++p; return j; }
+                    fail("',' or ']' expected");
+                }
+            }
+            case '"': j.kind = Json::String; j.s = string(); return j;
+            case 't': if (lit("true")) { j.kind = Json::Bool; j.b = true; return j; } fail("bad literal");
+            case 'f': if (lit("false")) { j.kind = Json::Bool; j.b = false; return j; } fail("bad literal");
+            case 'n': if (lit("null")) return j; fail("bad literal");
+            default: return number();
+        }
+    }
+};
+
+const char *kind_name(Json::Kind k) {
+    static const char *const names[] = {"null", "boolean", "integer", "number", "string", "array", "object"};
+    return names[k];
+}
+
+}  // namespace
+
+Json parse(const std::string &text) {
+    Reader r{text.data(), text.data() + text.size(), text.data()};
+    Json j = r.value(0);
+    r.ws();
+    if (r.p != r.end) r.fail("trailing characters");
+    return j;
+}
+
+const Json &Json::at(const std::string &key) const {
+    if (kind != Object) throw TypeError(std::string("cannot use at(key) with ") + kind_name(kind));
+    for (const auto &kv : obj)
+        if (kv.first == key) return kv.second;
+    throw std::out_of_range("key '" + key + "' not found");
+}
+
+const Json &Json::at(size_t index) const {
+    if (kind != Array) throw TypeError(std::string("cannot use at(index) with ") + kind_name(kind));
+    if (index >= arr.size()) throw std::out_of_range("array index " + std::to_string(index) + " is out of range");
+    return arr[index];
+}
+
+float Json::as_float() const {
+    if (kind == Int) return (float)i;
+    if (kind == Float) return (float)f;
+    throw TypeError(std::string("type must be number, but is ") + kind_name(kind));
+}
+
+int64_t Json::as_int() const {
+    if (kind == Int) return i;
+    if (kind == Float && std::nearbyint(f) == f && std::fabs(f) < 9.2e18) return (int64_t)f;
+    throw TypeError(std::string("type must be integer, but is ") + kind_name(kind));
+}
+
+// ---- writer ------------------------------------------------------------------------------------------
+void append_float(std::string &out, float v) {
+    if (!std::isfinite(v)) { out += "null"; return; }
+    char buf[32];
+    const int n = std::snprintf(buf, sizeof buf, "%.9g", (double)v);
+    out.append(buf, (size_t)n);
+    // keep it a JSON *float* token, as nlohmann does for floating values ("3.0", not "3")
+    if (std::strpbrk(buf, ".eE") == nullptr) out += ".0";
+}
+
+void append_int(std::string &out, int64_t v) {
+    char buf[24];
+    const int n = std::snprintf(buf, sizeof buf, "%lld", (long long)v);
+    out.append(buf, (size_t)n);
+}
+
+namespace {
+
+template <class Row>
+void write_float_row(std::string &out, const Row &row) {
+    out.push_back('[');
+    bool first = true;
+    for (const float v : row) {
+        if (!first) out.push_back(',');
+        first = false;
+        append_float(out, v);
+    }
+    out.push_back(']');
+}
+
+template <class It>
+void write_int_list(std::string &out, It b, It e) {
+    out.push_back('[');
+    for (It it = b; it != e; ++it) {
+        if (it != b) out.push_back(',');
+        append_int(out, (int64_t)*it);
+    }
+    out.push_back(']');
+}
+
+// std::array<std::array<T, COLS>, ROWS> from a JSON array of arrays: shorter input throws (at()), longer input is
+// read up to the array's extent -- nlohmann's from_json for std::array behaves the same way
+template <size_t ROWS, size_t COLS>
+void read_floats(const Json &j, std::array<std::array<float, COLS>, ROWS> &out) {
+    for (size_t r = 0; r < ROWS; ++r)
+        for (size_t c = 0; c < COLS; ++c) out[r][c] = j.at(r).at(c).as_float();
+}
+
+template <size_t ROWS, size_t COLS>
+void read_ids(const Json &j, std::array<std::array<faiss_idx_t, COLS>, ROWS> &out) {
+    for (size_t r = 0; r < ROWS; ++r)
+        for (size_t c = 0; c < COLS; ++c) out[r][c] = j.at(r).at(c).as_int();
+}
+
+}  // namespace
+
+// ---- handlers ----------------------------------------------------------------------------------------
+std::string handle_query(const Server &server) {
+    std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> centroids;
+    server.retrieve_centroids(centroids);
+    std::string out;
+    out.reserve(centroids.size() * PRECISE_VECTOR_DIMENSIONS * 12);
+    out.push_back('[');
+    for (size_t i = 0; i < centroids.size(); ++i) {
+        if (i) out.push_back(',');
+        write_float_row(out, centroids[i]);
+    }
+    out.push_back(']');
+    return out;
+}
+
+std::string handle_coarse_search(const Server &server, const std::string &body) {
+    const Json req = parse(body);
+    std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> precise_query;
+    std::array<std::array<faiss_idx_t, NPROBE>, NQUERY> nearest_centroids;
+    read_floats(req.at("preciseQuery"), precise_query);
+    read_ids(req.at("nearestCentroidIndexes"), nearest_centroids);
+
+    std::vector<float> coarse_distance_scores;
+    std::vector<faiss::idx_t> coarse_vector_indexes;
+    std::array<size_t, NQUERY> list_sizes_per_query;
+    server.coarseSearch(precise_query, nearest_centroids, coarse_distance_scores, coarse_vector_indexes, list_sizes_per_query);
+
+    std::string out;
+    out.reserve(coarse_distance_scores.size() * 20 + 128);
+    out += "{\"coarseDistanceScores\":";
+    write_float_row(out, coarse_distance_scores);
+    out += ",\"coarseVectorIndexes\":";
+    write_int_list(out, coarse_vector_indexes.begin(), coarse_vector_indexes.end());
+    out += ",\"listSizesPerQuery\":";
+    write_int_list(out, list_sizes_per_query.begin(), list_sizes_per_query.end());
+    out.push_back('}');
+    return out;
+}
+
+std::string handle_precise_search(const Server &server, const std::string &body) {
+    const Json req = parse(body);
+    std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> precise_query;
+    std::array<std::array<faiss_idx_t, COARSE_PROBE>, NQUERY> nearest_coarse_vectors_id;
+    read_floats(req.at("preciseQuery"), precise_query);
+    read_ids(req.at("nearestCoarseVectorIndexes"), nearest_coarse_vectors_id);
+
+    std::array<std::array<float, COARSE_PROBE>, NQUERY> precise_distance_scores;
+    server.preciseSearch(precise_query, nearest_coarse_vectors_id, precise_distance_scores);
+
+    std::string out = "{\"preciseDistanceScores\":[";
+    for (size_t q = 0; q < (size_t)NQUERY; ++q) {
+        if (q) out.push_back(',');
+        write_float_row(out, precise_distance_scores[q]);
+    }
+    out += "]}";
+    return out;
+}
+
+std::string handle_precise_vector_pir(Server &server, const std::string &body) {
+    const Json req = parse(body);
+    std::array<std::array<faiss_idx_t, K>, NQUERY> ids;
+    read_ids(req.at("nearestPreciseVectorIndexes"), ids);
+
+    // NQUERY * K * 128 floats: on the heap (the reference keeps it on the handler's stack)
+    auto results = std::make_unique<std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY>>();
+    server.preciseVectorPIR(ids, *results);
+
+    std::string out;
+    out.reserve((size_t)NQUERY * K * PRECISE_VECTOR_DIMENSIONS * 6);
+    out += "{\"queryResults\":[";
+    for (size_t q = 0; q < (size_t)NQUERY; ++q) {
+        if (q) out.push_back(',');
+        out.push_back('[');
+        for (size_t r = 0; r < (size_t)K; ++r) {
+            if (r) out.push_back(',');
+            write_float_row(out, (*results)[q][r]);
+        }
+        out.push_back(']');
+    }
+    out += "]}";
+    return out;
+}
+
+std::string handle(Server &server, const std::string &route, const std::string &body) {
+    if (route == "query") return handle_query(server);
+    if (route == "coarsesearch") return handle_coarse_search(server, body);
+    if (route == "precisesearch") return handle_precise_search(server, body);
+    if (route == "precise-vector-pir") return handle_precise_vector_pir(server, body);
+    throw std::out_of_range("no such route: " + route);
+}
+
+}  // namespace wire

@@ -12,6 +12,8 @@
 #include <type_traits>
 
 #include "../../include/server/server_lib.h"
+#include "../../include/server/wire.h"
+#include "../../include/client/client_lib.h"
 
 // ---- signature pins (reference include/server/server_lib.h:19-49) ----
 using Q = std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY>;
@@ -240,6 +242,66 @@ int main(int argc, char **argv) {
             std::printf("protocol on a 64-cluster Gaussian mixture: Recall@1 %.3f Recall@10 %.3f Recall@100 %.3f MRR@10 %.3f\n",
                         recall_at[0], recall_at[1], recall_at[2], mrr10);
             EXPECT(recall_at[1] >= 0.9 && recall_at[2] >= 0.8 && mrr10 >= 0.9);
+
+            // ---- the same run through the client library and the JSON wire format (include/client/client_lib.h,
+            // include/server/wire.h): main() of the reference client, src/client/client.cpp:7-80, with an in-process
+            // transport.  Every intermediate must equal what the direct Server calls above produced.
+            wire::InProcessTransport link(*srv);
+            set_transport(&link);
+            ping_server();
+            std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> c_cents;
+            get_centroids(c_cents);
+            EXPECT(c_cents.size() == cents.size() && std::memcmp(c_cents.data(), cents.data(), cents.size() * sizeof cents[0]) == 0);
+            std::array<std::vector<DistanceIndexData>, NQUERY> c_near;
+            sort_nearest_centroids(q2, c_cents, c_near);
+            for (int i = 0; i < NQUERY; i++) {
+                EXPECT(c_near[i].size() == static_cast<size_t>(NLIST));
+                for (int j = 0; j < NPROBE; j++) EXPECT(c_near[i][j].idx == probe[i][j]);
+                float distance = 0.0;                                            // the reference's host loop, bit for bit
+                for (int k = 0; k < 128; k++) distance += std::pow(q2[i][k] - cents[c_near[i][0].idx][k], 2);
+                EXPECT(std::memcmp(&distance, &c_near[i][0].distance, 4) == 0);
+            }
+            std::vector<float> c_cs; std::vector<faiss_idx_t> c_ci; std::array<size_t, NQUERY> c_sz{};
+            get_coarse_scores(c_near, q2, c_cs, c_ci, c_sz);
+            EXPECT(c_sz == sz && c_ci == ci && c_cs.size() == cs.size() && std::memcmp(c_cs.data(), cs.data(), cs.size() * 4) == 0);
+            std::array<std::vector<DistanceIndexData>, NQUERY> c_coarse;
+            compute_nearest_coarse_vectors(c_cs, c_ci, c_sz, c_coarse);
+            std::array<std::array<float, COARSE_PROBE>, NQUERY> c_pd;
+            get_precise_scores(c_coarse, q2, c_pd);
+            bool same_coarse = true;
+            for (int i = 0; i < NQUERY; i++)
+                for (int j = 0; j < COARSE_PROBE; j++) same_coarse = same_coarse && c_coarse[i][j].idx == coarse_ids[i][j];
+            EXPECT(same_coarse);
+            if (same_coarse) EXPECT(std::memcmp(c_pd.data(), pd.data(), sizeof pd) == 0);
+            auto c_best = std::make_unique<std::array<std::array<DistanceIndexData, COARSE_PROBE>, NQUERY>>();
+            compute_nearest_precise_vectors(c_pd, c_coarse, *c_best);
+            auto c_rows = std::make_unique<std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY>>();
+            std::array<std::array<faiss_idx_t, K>, NQUERY> c_ids;
+            get_precise_vectors_pir(*c_best, *c_rows, c_ids);
+            std::vector<int> gt_ids(static_cast<size_t>(NQUERY) * K);             // exact ground truth, the .ivecs layout
+            for (int i = 0; i < NQUERY; i++) {
+                std::vector<std::pair<double, int64_t>> gt;
+                for (int64_t j = 0; j < NBASE; j++) {
+                    double dd = 0;
+                    for (int t = 0; t < 128; t++) { const double df = double(b2[j * 128 + t]) - double(q2[i][t]); dd += df * df; }
+                    gt.push_back({dd, j});
+                }
+                std::sort(gt.begin(), gt.end());
+                for (int j = 0; j < K; j++) gt_ids[i * K + j] = static_cast<int>(gt[j].second);
+                for (int j = 0; j < K; j++)                                        // the returned vectors are the base rows
+                    EXPECT(std::memcmp((*c_rows)[i][j].data(), b2.data() + c_ids[i][j] * 128, 512) == 0);
+                for (int j = 1; j < K; j++) EXPECT((*c_best)[i][j - 1].distance <= (*c_best)[i][j].distance);
+            }
+            const RecallStats st = compute_recall_stats(c_ids, gt_ids, K);
+            std::printf("client library over the wire format: Recall@1 %.3f Recall@10 %.3f Recall@100 %.3f MRR@1 %.3f MRR@10 %.3f MRR@100 %.3f; "
+                        "%zu request bytes, %zu response bytes\n", st.recall_1, st.recall_10, st.recall_100, st.mrr_1, st.mrr_10, st.mrr_100,
+                        link.bytes_sent, link.bytes_received);
+            EXPECT(st.recall_10 >= 0.9 && st.recall_100 >= 0.8 && st.mrr_10 >= 0.9 && link.bytes_sent > 0 && link.bytes_received > 0);
+            // a malformed body surfaces as an exception, as it does under Drogon
+            bool threw = false;
+            try { link.post("coarsesearch", "{\"preciseQuery\": [[1,2]]}"); } catch (const std::out_of_range &) { threw = true; }
+            EXPECT(threw);
+            set_transport(nullptr);
         }
     }
 

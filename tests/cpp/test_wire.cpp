@@ -1,0 +1,132 @@
+// test_wire.cpp -- CPU-only checks of the JSON wire format (include/server/wire.h) and of the recall / MRR
+// bookkeeping of the client library (include/client/client_lib.h).  No device is touched.
+//   test_wire selftest            JSON reader / writer unit checks; exit code 0 when all pass
+//   test_wire recall <file>       file: int64 observed[NQUERY*K], int32 gt_nn, int32 gt[NQUERY*gt_nn]; prints the six figures
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <string>
+
+#include "client_lib.h"
+#include "wire.h"
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+template <class E, class F>
+static bool throws(F &&f) {
+    try { f(); } catch (const E &) { return true; } catch (...) { return false; }
+    return false;
+}
+
+static int selftest() {
+    using namespace wire;
+    // documents of the protocol's shape
+    const Json j = parse(" {\"preciseQuery\": [[1, 2.5, -3e2], [0.1, 1E-3, 7]], \"ids\": [[9007199254740993, -1]], \"s\": \"a\\n\\u0041\", \"t\": true, \"n\": null} ");
+    EXPECT(j.kind == Json::Object && j.obj.size() == 5);
+    EXPECT(j.at("preciseQuery").at(0).at(1).as_float() == 2.5f);
+    EXPECT(j.at("preciseQuery").at(0).at(2).as_float() == -300.0f);
+    EXPECT(j.at("preciseQuery").at(1).at(0).as_float() == 0.1f);
+    EXPECT(j.at("ids").at(0).at(0).as_int() == 9007199254740993ll);          // beyond 2^53: integers stay exact
+    EXPECT(j.at("ids").at(0).at(1).as_int() == -1);
+    EXPECT(j.at("s").s == "a\nA" && j.at("t").b && j.at("n").kind == Json::Null);
+    EXPECT(j.at("preciseQuery").at(1).at(2).as_int() == 7);
+    // error behaviour the handlers rely on
+    EXPECT(throws<std::out_of_range>([&] { j.at("missing"); }));
+    EXPECT(throws<std::out_of_range>([&] { j.at("ids").at(1); }));
+    EXPECT(throws<TypeError>([&] { j.at("n").as_float(); }));
+    EXPECT(throws<TypeError>([&] { j.at("s").as_int(); }));
+    EXPECT(throws<TypeError>([&] { j.at("t").at(0); }));
+    EXPECT(throws<TypeError>([&] { parse("[1.5]").at(0).as_int(); }));
+    for (const char *bad : {"", "{", "[1,]", "{\"a\" 1}", "[1 2]", "nul", "[01]", "[1.]", "[1e]", "\"abc", "[1] x", "{\"a\":1,}", "[\"\\q\"]", "-"})
+        EXPECT(throws<ParseError>([&] { parse(bad); }));
+    EXPECT(parse("[]").arr.empty() && parse("{}").obj.empty() && parse("  3 ").as_int() == 3);
+    // writer: every float survives a round trip; integral floats stay float tokens; non-finite -> null
+    const float samples[] = {0.0f, -0.0f, 1.0f, 255.0f, 0.1f, 1e-30f, 3.4028235e38f, 1.17549435e-38f, 1e-45f, 16777217.0f, 123456.789f, -2.5e-7f};
+    for (float v : samples) {
+        std::string s;
+        append_float(s, v);
+        const Json r = parse(s);
+        EXPECT(r.kind == Json::Float);
+        EXPECT(r.as_float() == v);
+    }
+    unsigned x = 12345u;                                                       // a few thousand bit patterns
+    for (int i = 0; i < 20000; ++i) {
+        x = x * 1664525u + 1013904223u;
+        float v;
+        std::memcpy(&v, &x, 4);
+        if (!std::isfinite(v)) continue;
+        std::string s;
+        append_float(s, v);
+        const float back = parse(s).as_float();
+        EXPECT(std::memcmp(&back, &v, 4) == 0 || (back == 0.0f && v == 0.0f));
+    }
+    std::string s;
+    append_float(s, std::numeric_limits<float>::infinity());
+    s += ",";
+    append_float(s, std::nanf(""));
+    EXPECT(s == "null,null");
+    s.clear();
+    append_int(s, std::numeric_limits<int64_t>::min());
+    EXPECT(parse(s).as_int() == std::numeric_limits<int64_t>::min());
+    // routes: an unknown route is refused before the server is touched
+    { Server idle; EXPECT(throws<std::out_of_range>([&] { handle(idle, "nope", ""); })); }
+    // client without a transport
+    set_transport(nullptr);
+    EXPECT(throws<std::runtime_error>([&] { ping_server(); }));
+    // client-side bookkeeping that needs no server
+    {
+        std::vector<float> scores;
+        std::vector<faiss_idx_t> ids;
+        std::array<size_t, NQUERY> sizes;
+        for (size_t q = 0; q < (size_t)NQUERY; ++q) {
+            sizes[q] = (size_t)COARSE_PROBE + q;
+            for (size_t i = 0; i < sizes[q]; ++i) { scores.push_back((float)((i * 7919 + q) % 251)); ids.push_back((faiss_idx_t)(1000 * q + i)); }
+        }
+        std::array<std::vector<DistanceIndexData>, NQUERY> nearest;
+        compute_nearest_coarse_vectors(scores, ids, sizes, nearest);
+        for (size_t q = 0; q < (size_t)NQUERY; ++q) {
+            EXPECT(nearest[q].size() == sizes[q]);
+            for (size_t i = 1; i < nearest[q].size(); ++i)                     // ascending, ties in arrival order
+                EXPECT(nearest[q][i - 1].distance < nearest[q][i].distance ||
+                       (nearest[q][i - 1].distance == nearest[q][i].distance && nearest[q][i - 1].idx < nearest[q][i].idx));
+        }
+        sizes[2] = (size_t)COARSE_PROBE - 1;
+        EXPECT(throws<std::runtime_error>([&] { compute_nearest_coarse_vectors(scores, ids, sizes, nearest); }));
+        std::array<std::vector<DistanceIndexData>, NQUERY> few;
+        std::vector<float> cs; std::vector<faiss_idx_t> ci; std::array<size_t, NQUERY> ls;
+        std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> query{};
+        EXPECT(throws<std::runtime_error>([&] { get_coarse_scores(few, query, cs, ci, ls); }));   // fewer than NPROBE centroids
+    }
+    std::printf(failures ? "selftest: %d failure(s)\n" : "selftest: ok\n", failures);
+    return failures ? 1 : 0;
+}
+
+static int recall(const char *path) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { std::printf("cannot open %s\n", path); return 2; }
+    std::array<std::array<faiss_idx_t, K>, NQUERY> observed;
+    in.read(reinterpret_cast<char *>(observed.data()), sizeof observed);
+    int32_t gt_nn = 0;
+    in.read(reinterpret_cast<char *>(&gt_nn), 4);
+    std::vector<int> gt((size_t)NQUERY * (size_t)(gt_nn > 0 ? gt_nn : 0));
+    in.read(reinterpret_cast<char *>(gt.data()), (std::streamsize)(gt.size() * 4));
+    if (!in) { std::printf("short file\n"); return 2; }
+    try {
+        const RecallStats s = compute_recall_stats(observed, gt, (size_t)gt_nn);
+        std::printf("%.9g %.9g %.9g %.9g %.9g %.9g\n", s.recall_1, s.recall_10, s.recall_100, s.mrr_1, s.mrr_10, s.mrr_100);
+    } catch (const std::exception &e) {
+        std::printf("error: %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && std::strcmp(argv[1], "selftest") == 0) return selftest();
+    if (argc >= 3 && std::strcmp(argv[1], "recall") == 0) return recall(argv[2]);
+    std::printf("usage: test_wire selftest | recall <file>\n");
+    return 2;
+}

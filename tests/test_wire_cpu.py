@@ -1,0 +1,79 @@
+"""CPU tests of the JSON wire format and of the client library's recall / MRR bookkeeping, through the compiled binary
+tests/cpp/test_wire (built by make -C prefhetch_amd/csrc).  The recall figures are checked against a numpy
+restatement of /root/reference/src/client/client_lib.cpp:243-337."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "tests", "cpp", "test_wire")
+NQUERY, K = 5, 100
+
+
+def _need_bin():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "prefhetch_amd", "csrc")])
+    assert os.path.exists(BIN)
+
+
+def test_json_reader_writer_and_error_behaviour():
+    _need_bin()
+    r = subprocess.run([BIN, "selftest"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "selftest: ok" in r.stdout, r.stdout + r.stderr
+
+
+def recall_reference(observed, gt, gt_nn):
+    """the reference's counting: ground-truth neighbour j < K is a hit at the position k < K where it shows up"""
+    rec = np.zeros(3)
+    mrr = np.zeros(3, dtype=np.float32)
+    for i in range(NQUERY):
+        for j in range(K):
+            hits = np.nonzero(observed[i] == gt[i * gt_nn + j])[0]
+            if len(hits) == 0:
+                continue
+            k = int(hits[0])
+            for a, lim in enumerate((1, 10, 100)):
+                if k < lim:
+                    rec[a] += 1
+                    if j == 0:
+                        mrr[a] = np.float32(mrr[a] + np.float32(1.0) / np.float32(k + 1))
+    return [np.float32(rec[0] / (1 * NQUERY)), np.float32(rec[1] / (10 * NQUERY)), np.float32(rec[2] / (100 * NQUERY))] + \
+           [np.float32(m / np.float32(NQUERY)) for m in mrr]
+
+
+@pytest.mark.parametrize("seed,gt_nn,overlap", [(1, 100, 1.0), (2, 100, 0.5), (3, 128, 0.9), (4, 100, 0.0), (5, 200, 0.7)])
+def test_recall_and_mrr_match_the_reference_definition(tmp_path, seed, gt_nn, overlap):
+    _need_bin()
+    rng = np.random.default_rng(seed)
+    gt = np.stack([rng.permutation(100000)[:gt_nn] for _ in range(NQUERY)]).astype(np.int32)
+    observed = np.empty((NQUERY, K), dtype=np.int64)
+    for i in range(NQUERY):
+        row = gt[i, :K].astype(np.int64).copy()
+        rng.shuffle(row[: max(2, int(K * 0.3))])                       # perturb the head
+        miss = rng.random(K) >= overlap
+        row[miss] = 200000 + rng.integers(0, 1000, miss.sum())          # ids outside the ground truth (may repeat)
+        observed[i] = row
+    path = tmp_path / "case.bin"
+    with open(path, "wb") as f:
+        f.write(observed.tobytes())
+        f.write(np.int32(gt_nn).tobytes())
+        f.write(gt.tobytes())
+    r = subprocess.run([BIN, "recall", str(path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = [np.float32(x) for x in r.stdout.split()]
+    exp = recall_reference(observed, gt.reshape(-1), gt_nn)
+    assert got == exp, (got, exp)
+
+
+def test_recall_rejects_short_ground_truth(tmp_path):
+    _need_bin()
+    path = tmp_path / "short.bin"
+    with open(path, "wb") as f:
+        f.write(np.zeros((NQUERY, K), dtype=np.int64).tobytes())
+        f.write(np.int32(50).tobytes())
+        f.write(np.zeros((NQUERY, 50), dtype=np.int32).tobytes())
+    r = subprocess.run([BIN, "recall", str(path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "K greater than nearest neigbours" in r.stdout
