@@ -109,6 +109,18 @@ pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, 
  * allocated on first use: call once outside graph capture. */
 pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
 
+/* Server side of the encrypted precise search (the step the reference's TODOs at include/client/client_lib.h:14,28-30
+ * and the "preciseQuery" fields of src/server/controllers/Query.cc:37,80 leave in the clear): packs base rows into
+ * plaintext polynomials such that, for a query polynomial q(X) = sum_i q_i X^i (i < d), coefficient d*j of
+ * q(X) * p(X) mod (X^N + 1) is the inner product <q, row_j>:
+ *     p(X) = sum_{j < rows_per_poly} sum_{i < d} x[ids[p][j]][i] * X^(d*j - i),     X^(-i) = -X^(N-i).
+ * Row values are rounded to the nearest integer (|v| < 2^24); out[p][l][c] is the coefficient's canonical residue
+ * mod q_l, coefficient form -- follow with pf_ntt_forward to obtain the NTT-form plaintexts pf_ct_pt_mul takes.
+ * ids [n_polys][rows_per_poly] (device); an id < 0 or >= nb contributes a zero row.  rows_per_poly <= N / d.
+ * No allocation, no synchronisation. */
+pf_status pf_pack_rows(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly,
+                       uint64_t *out, pf_stream stream);
+
 /* ---- plaintext distance stages ---------------------------------------------------------------- */
 /* faiss::IndexFlatL2(d) + add(nb, xb): copies the base matrix [nb][d] fp32 (host or device pointer)
  * into HBM and precomputes row norms.  Blocking. */

@@ -172,6 +172,36 @@ def gather_rows(base, ids):
     return out
 
 
+def pack_rows(base, ids, N, moduli):
+    """Plaintext packing of the encrypted precise search (the build's own encoding; the reference leaves this step as
+    TODOs, include/client/client_lib.h:14,28-30): p(X) = sum_j sum_i x[ids[p][j]][i] X^(d*j - i) mod (X^N + 1), values
+    rounded to integers, out[p][l][c] canonical mod moduli[l].  ids [n_polys][rows_per_poly]; an id outside the base is a
+    zero row.  Written from the definition (exponent arithmetic with sign), not from the kernel's inverse mapping."""
+    base = np.asarray(base, np.float32)
+    ids = np.asarray(ids, np.int64)
+    nb, d = base.shape
+    n_polys, rows = ids.shape
+    assert rows * d <= N
+    out = np.zeros((n_polys, len(moduli), N), dtype=np.uint64)
+    for p in range(n_polys):
+        coeff = [0] * N
+        for j in range(rows):
+            rid = int(ids[p, j])
+            if rid < 0 or rid >= nb:
+                continue
+            row = np.rint(base[rid]).astype(np.int64)
+            for i in range(d):
+                e = d * j - i
+                sign = 1
+                if e < 0:
+                    e += N
+                    sign = -1
+                coeff[e] += sign * int(row[i])
+        for l, q in enumerate(moduli):
+            out[p, l] = np.array([c % q for c in coeff], dtype=np.uint64)
+    return out
+
+
 def flat_l2_search(xb, xq, k, mode=0, threads=0, f32=False):
     xb = np.ascontiguousarray(xb, np.float32)
     xq = np.ascontiguousarray(xq, np.float32)

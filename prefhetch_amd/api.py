@@ -127,6 +127,20 @@ class RnsContext:
         return out
 
 
+    def pack_rows(self, flat, ids, out=None):
+        """Plaintext polynomials of the encrypted precise search: ids [n_polys, rows_per_poly] (int64, device) rows of
+        the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_)."""
+        if ids.dim() != 2:
+            raise ValueError("ids must be [n_polys, rows_per_poly]")
+        n_polys, rows = ids.shape
+        if out is None:
+            out = torch.empty((n_polys, self.L, self.N), dtype=torch.int64, device=self.device)
+        pi, po = _req(ids, torch.int64, self.device_index, "ids"), _req(out, torch.int64, self.device_index, "out")
+        if out.numel() != n_polys * self.L * self.N:
+            raise ValueError("out must hold n_polys * L * N residues")
+        check(lib.pf_pack_rows(self._h, flat._h, pi, n_polys, rows, po, _stream(self.device)), "pf_pack_rows")
+        return out
+
     def key_switch_(self, target, ksk, ct):
         """This context holds the key moduli (special prime last).  target [B,D,N], ksk [D,2,D+1,N] (NTT form),
         ct [B,2,D,N]: the switched polynomial is added into ct in place."""

@@ -35,4 +35,7 @@ struct DeviceGuard {
 
 inline hipStream_t as_stream(pf_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// base matrix of a flat index, for the translation units that read it (defined in pf_flat.hip; not part of the ABI)
+const float *flat_base_device(const pf_flat *f, size_t *nb, uint32_t *d, int *device);
+
 }  // namespace pf

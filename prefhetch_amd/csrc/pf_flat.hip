@@ -505,6 +505,16 @@ pf_status ensure_ws(pf_flat *f, size_t bytes) {
 
 }  // namespace
 
+namespace pf {
+const float *flat_base_device(const pf_flat *f, size_t *nb, uint32_t *d, int *device) {
+    if (!f) return nullptr;
+    if (nb) *nb = f->nb;
+    if (d) *d = f->d;
+    if (device) *device = f->device;
+    return f->xb;
+}
+}  // namespace pf
+
 extern "C" {
 
 pf_status pf_flat_destroy(pf_flat *f) {

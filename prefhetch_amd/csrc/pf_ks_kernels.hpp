@@ -98,4 +98,38 @@ __global__ void __launch_bounds__(256) k_ks_moddown(KsArgs p) {
     }
 }
 
+// ---- plaintext packing for the encrypted inner products (pf_pack_rows) ---------------------------------
+// One thread per output coefficient: coefficient c of polynomial p, limb l.  Row j > 0 occupies coefficients
+// d*j - i (i < d), row 0 occupies coefficient 0 and, negated, the top coefficients N - i (X^-i = -X^(N-i)).
+struct PackArgs {
+    const LimbDev *limbs;
+    const float *xb; const int64_t *ids; uint64_t *out;
+    size_t nb; uint32_t d, L, logn, rows_per_poly;
+};
+
+__global__ void __launch_bounds__(256) k_pack_rows(PackArgs p) {
+    const uint32_t N = 1u << p.logn, per = N / 256;
+    const size_t b = blockIdx.x;
+    const uint32_t c = (uint32_t)(b % per) * 256 + threadIdx.x;
+    const size_t pl = b / per;                                   // polynomial * L + limb
+    const uint32_t l = (uint32_t)(pl % p.L);
+    const size_t poly = pl / p.L;
+    uint32_t j = 0, i = 0;
+    bool neg = false, live = true;
+    if (c != 0) {
+        const uint32_t jj = (c + p.d - 1) / p.d;
+        if (jj < p.rows_per_poly) { j = jj; i = jj * p.d - c; }
+        else if (N - c < p.d) { j = 0; i = N - c; neg = true; }
+        else live = false;
+    }
+    int64_t v = 0;
+    if (live) {
+        const int64_t id = p.ids[poly * p.rows_per_poly + j];
+        if (id >= 0 && (size_t)id < p.nb) v = (int64_t)rintf(p.xb[(size_t)id * p.d + i]);
+    }
+    if (neg) v = -v;
+    const uint64_t q = p.limbs[l].q;
+    p.out[pl * N + c] = v >= 0 ? (uint64_t)v : q - (uint64_t)(-v);
+}
+
 }  // namespace pf

@@ -258,6 +258,24 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);     // grid: 8 XCD streams x 2 polynomials per pair
 }
 
+pf_status pf_pack_rows(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly, uint64_t *out,
+                       pf_stream stream) {
+    if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");
+    if (n_polys == 0) return PF_OK;
+    if (!ids || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    size_t nb = 0; uint32_t d = 0; int dev = 0;
+    const float *xb = flat_base_device(idx, &nb, &d, &dev);
+    if (dev != c->device) return fail(PF_ERR_INVALID_ARG, "context and index live on different devices");
+    if (rows_per_poly == 0 || (size_t)rows_per_poly * d > c->N) return fail(PF_ERR_INVALID_ARG, "rows_per_poly must be in [1, N / d]");
+    const size_t blocks = n_polys * c->L * (c->N / 256);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many polynomials for one launch");
+    PF_GUARD(c->device);
+    PackArgs a{c->d_limbs, xb, ids, out, nb, d, c->L, c->logn, rows_per_poly};
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream) {
     if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
     if (B == 0) return PF_OK;

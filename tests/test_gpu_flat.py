@@ -179,3 +179,26 @@ def test_ivfpq_search_lists_bit_exact(pf, d, M, nlist, n, nq, nprobe):
     assert (sizes == sr).all() and int(sizes.sum()) == Dr.size
     assert (I.cpu().numpy() == Ir).all()
     assert (D.cpu().numpy().view(np.uint32) == Dr.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("N,qs,rows", [(1024, oracle.BFV_DEFAULT[1024], 8), (8192, oracle.BFV_DEFAULT[8192][:4], 64),
+                                       (8192, oracle.BFV_DEFAULT[8192][:4], 8), (4096, oracle.BFV_DEFAULT[4096][:2], 32)])
+def test_pack_rows_matches_the_definition(N, qs, rows):
+    """pf_pack_rows (plaintext polynomials of the encrypted precise search) against oracle.pack_rows, bit-exact,
+    including ids outside the base (zero rows), and fractional values (rounded to nearest)."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(N + rows)
+    nb, d = 3000, 128
+    base = rng.integers(0, 256, (nb, d)).astype(np.float32)
+    base[7] += np.float32(0.25)                      # rint
+    base[8] = -base[8]                               # negative entries
+    ids = rng.integers(0, nb, (5, rows)).astype(np.int64)
+    ids[0, 0], ids[1, rows - 1], ids[2, 1], ids[3, 0] = 7, 8, -1, nb
+    flat = pf.FlatL2(base, dev)
+    ctx = pf.RnsContext(N, qs, dev)
+    got = pf.to_host_u64(ctx.pack_rows(flat, torch.from_numpy(ids).to(dev)))
+    exp = oracle.pack_rows(base, ids, N, qs)
+    assert got.shape == exp.shape and (got == exp).all()
+    with pytest.raises(pf.PfError):
+        ctx.pack_rows(flat, torch.zeros((1, N // d + 1), dtype=torch.int64, device=dev))

@@ -215,3 +215,25 @@ if _HAVE_HYPOTHESIS:
         assert [int(x) for x in A] == B.ntt_direct([int(x) for x in a], q, o.psi(0))
         prod = o.ntt_inverse(o.dyadic_mul(A, o.ntt_forward(b)))
         assert [int(x) for x in prod] == B.negacyclic_mul([int(x) for x in a], [int(x) for x in b], q)
+
+
+def test_pack_rows_encoding_yields_inner_products():
+    """the packing of the encrypted precise search: coefficient d*j of q(X) p(X) mod (X^N + 1) is <q, row_j>
+    (checked with the big-integer schoolbook product, no NTT involved)"""
+    from oracle import bigint_ref as B
+    rng = np.random.default_rng(11)
+    N, d, rows = 1024, 128, 8
+    base = rng.integers(0, 256, (40, d)).astype(np.float32)
+    ids = np.array([[3, 39, 0, 17, 5, 5, 21, 8], [1, 2, -1, 4, 400, 6, 7, 9]], dtype=np.int64)   # -1 / 400: outside the base
+    qmod = 0x7E00001
+    packed = oracle.pack_rows(base, ids, N, [qmod])
+    query = rng.integers(0, 256, d)
+    qpoly = [int(v) for v in query] + [0] * (N - d)
+    for p in range(2):
+        coeff = [int(c) if int(c) < qmod // 2 else int(c) - qmod for c in packed[p, 0]]           # centred lift
+        prod = B.negacyclic_mul(qpoly, coeff, 1 << 62)
+        for j in range(rows):
+            rid = int(ids[p, j])
+            want = int(np.dot(query, base[rid].astype(np.int64))) if 0 <= rid < 40 else 0
+            got = prod[d * j] if prod[d * j] < (1 << 61) else prod[d * j] - (1 << 62)
+            assert got == want, (p, j)
