@@ -109,6 +109,13 @@ pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, 
  * allocated on first use: call once outside graph capture. */
 pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
 
+/* Same, with every input ciphertext multiplied by `fanout` consecutive plaintexts: out[b] = ct[b / fanout] x pt[b],
+ * b < B; ct holds ceil(B / fanout) ciphertexts, pt_ntt B plaintexts, out B ciphertexts (must not alias ct when
+ * fanout > 1).  This is the shape of the encrypted precise search: one query ciphertext against
+ * ceil(COARSE_PROBE * d / N) packed blocks of candidate rows. */
+pf_status pf_ct_pt_mul_fanout(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, uint64_t *out, size_t B, uint32_t fanout,
+                              int flags, pf_stream stream);
+
 /* Server side of the encrypted precise search (the step the reference's TODOs at include/client/client_lib.h:14,28-30
  * and the "preciseQuery" fields of src/server/controllers/Query.cc:37,80 leave in the clear): packs base rows into
  * plaintext polynomials such that, for a query polynomial q(X) = sum_i q_i X^i (i < d), coefficient d*j of

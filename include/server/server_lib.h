@@ -60,6 +60,19 @@ class Server {
     // list-contiguous codes [ntotal][32] and ids [ntotal], list offsets [NLIST+1].
     void export_index(std::vector<float> &centroids, std::vector<float> &codebooks, std::vector<uint8_t> &codes,
                       std::vector<faiss::idx_t> &ids, std::vector<uint64_t> &list_offsets) const;
+    // The encrypted form of preciseSearch -- the step the reference's TODOs leave in the clear
+    // (include/client/client_lib.h:14,28-30): the query arrives as BFV ciphertexts of the polynomial sum_i q_i X^i
+    // (include/client/bfv.h: encode_query), ring degree 8192 over SEAL's BFVDefault(8192) data primes, SEAL's
+    // Ciphertext::data() layout [2][L][N], already in HBM.  result block b of query i is a ciphertext whose plaintext
+    // carries <q_i, x_{ids[i][64 b + j]}> at coefficient 128 j (decode_inner_products); the client adds its own
+    // ||q||^2 and the row norms to obtain the squared distances preciseSearch returns.
+    static constexpr uint32_t ENC_RING_DEGREE = 8192, ENC_LIMBS = 4;
+    static constexpr uint64_t ENC_MODULI[ENC_LIMBS] = {0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001};
+    static constexpr uint32_t ENC_ROWS_PER_POLY = ENC_RING_DEGREE / PRECISE_VECTOR_DIMENSIONS;
+    static constexpr uint32_t ENC_POLYS_PER_QUERY = (COARSE_PROBE + ENC_ROWS_PER_POLY - 1) / ENC_ROWS_PER_POLY;
+    void preciseSearchEncrypted(const uint64_t *query_ct_device /* [NQUERY][2][4][8192] */,
+                                const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &nearest_coarse_vector_idx,
+                                uint64_t *result_ct_device /* [NQUERY][ENC_POLYS_PER_QUERY][2][4][8192] */) const;
     // The executed flat-L2 shortlist of the protocol (client sort_nearest_centroids, src/client/client_lib.cpp:50-81)
     // on the server's IndexFlatL2 over the centroids: top-NPROBE centroid ids (and squared distances) per query.
     void nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,

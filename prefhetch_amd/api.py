@@ -127,6 +127,21 @@ class RnsContext:
         return out
 
 
+    def ct_pt_mul_fanout(self, ct, pt_ntt, fanout, out=None, flags=0):
+        """out[b] = ct[b // fanout] x pt_ntt[b]: ct [ceil(B/fanout),2,L,N], pt_ntt [B,L,N] -> out [B,2,L,N]."""
+        if int(fanout) < 1:
+            raise ValueError("fanout must be at least 1")
+        B = pt_ntt.numel() // (self.L * self.N)
+        if pt_ntt.numel() != B * self.L * self.N or ct.numel() != -(-B // fanout) * 2 * self.L * self.N:
+            raise ValueError("ct must hold ceil(B / fanout) ciphertexts for the B plaintexts of pt_ntt")
+        if out is None:
+            if flags & ACCUMULATE:
+                raise ValueError("ACCUMULATE needs an `out` operand")
+            out = torch.empty((B, 2, self.L, self.N), dtype=torch.int64, device=self.device)
+        pc, pp, po = (_req(t, torch.int64, self.device_index, n) for t, n in ((ct, "ct"), (pt_ntt, "pt_ntt"), (out, "out")))
+        check(lib.pf_ct_pt_mul_fanout(self._h, pc, pp, po, B, int(fanout), int(flags), _stream(self.device)), "pf_ct_pt_mul_fanout")
+        return out
+
     def pack_rows(self, flat, ids, out=None):
         """Plaintext polynomials of the encrypted precise search: ids [n_polys, rows_per_poly] (int64, device) rows of
         the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_)."""

@@ -258,6 +258,19 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);     // grid: 8 XCD streams x 2 polynomials per pair
 }
 
+pf_status pf_ct_pt_mul_fanout(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, uint64_t *out, size_t B, uint32_t fanout, int flags,
+                              pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (B == 0) return PF_OK;
+    if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (fanout == 0) return fail(PF_ERR_INVALID_ARG, "fanout must be at least 1");
+    if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
+    if (ct == out && fanout > 1) return fail(PF_ERR_INVALID_ARG, "out must not alias ct when ciphertexts fan out");
+    const size_t pairs = B * (size_t)c->L;
+    NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, pairs, c->L, 0u, 0u, fanout};
+    return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);
+}
+
 pf_status pf_pack_rows(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly, uint64_t *out,
                        pf_stream stream) {
     if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");

@@ -29,6 +29,7 @@ struct NttArgs {
     uint32_t L;
     uint32_t pt_broadcast;
     uint32_t ks_decomp;      // key switching: number of digits (data limbs); L above is then the key-modulus count K
+    uint32_t ct_fanout;      // ct x pt only: consecutive outputs that share one input ciphertext (0 or 1: none)
 };
 
 template <class A> struct ArithOf;
@@ -98,10 +99,11 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ct
     const uint32_t limb = (uint32_t)(m % p.L);
     const size_t ctidx = m / p.L;
     const size_t poly = (ctidx * 2 + (j & 1)) * p.L + limb;   // limb-polynomial index in [B][2][L]
+    const size_t src_poly = p.ct_fanout > 1 ? ((ctidx / p.ct_fanout) * 2 + (j & 1)) * p.L + limb : poly;
     const LimbDev &lm = p.limbs[limb];
     const A ar = ArithOf<A>::make(lm);
     const uint64_t *pt = p.pt + ((p.pt_broadcast ? 0 : ctidx) * p.L + limb) * G::N;
-    body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + poly * G::N, pt,
+    body_ctpt<G, A, FLAGS>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), p.src + src_poly * G::N, pt,
                            p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
 }
 

@@ -115,11 +115,12 @@ struct Server::Impl {
     pf_flat *base = nullptr;        // NBASE x 128 fp32 in HBM (reference: m_DatasetBase)
     pf_flat *centroids = nullptr;   // NLIST x 128 fp32 in HBM (reference: m_Quantizer / m_Index->quantizer)
     pf_ivfpq *ivfpq = nullptr;      // inverted lists + PQ codes (reference: m_Index)
+    pf_ctx *ring = nullptr;         // RNS ring of the encrypted round: N = 8192, SEAL BFVDefault data primes
     std::vector<float> h_centroids, h_codebooks;
     size_t nb = 0, nlist = 0;
     // the reference's handlers run on one Drogon loop thread; this lock makes concurrent const calls safe anyway
     mutable std::mutex lock;
-    mutable DevBuf d_query, d_ids, d_out, d_out2;
+    mutable DevBuf d_query, d_ids, d_out, d_out2, d_pt;
 
     ~Impl() {
         reset();
@@ -128,7 +129,8 @@ struct Server::Impl {
         if (base) pf_flat_destroy(base);
         if (centroids) pf_flat_destroy(centroids);
         if (ivfpq) pf_ivfpq_destroy(ivfpq);
-        base = nullptr; centroids = nullptr; ivfpq = nullptr;
+        if (ring) pf_ctx_destroy(ring);
+        base = nullptr; centroids = nullptr; ivfpq = nullptr; ring = nullptr;
     }
     // installs trained tables and creates the device objects
     void install(int dev, const float *base_rows, size_t n_base, std::vector<float> cent, std::vector<float> books) {
@@ -139,6 +141,7 @@ struct Server::Impl {
         check(pf_flat_create(&base, dev, base_rows, n_base, kD), "pf_flat_create(base)");
         check(pf_flat_create(&centroids, dev, h_centroids.data(), nlist, kD), "pf_flat_create(centroids)");
         check(pf_ivfpq_create(&ivfpq, dev, kD, static_cast<uint32_t>(nlist), kM, h_centroids.data(), h_codebooks.data()), "pf_ivfpq_create");
+        check(pf_ctx_create(&ring, dev, Server::ENC_RING_DEGREE, Server::ENC_LIMBS, Server::ENC_MODULI), "pf_ctx_create");
     }
     // IndexIVFPQ::add: assign to the nearest coarse centroid, encode the residual, append (ids = row numbers)
     void add(const float *x, size_t n) {
@@ -328,6 +331,29 @@ void Server::preciseSearch(const std::array<std::array<float, PRECISE_VECTOR_DIM
     check(pf_l2_gathered(im.base, static_cast<const float *>(im.d_query.ptr), static_cast<const int64_t *>(im.d_ids.ptr), NQUERY,
                          COARSE_PROBE, static_cast<float *>(im.d_out.ptr), nullptr), "pf_l2_gathered");
     check(pf_memcpy_d2h(im.device, precise_distance_scores.data(), im.d_out.ptr, sizeof precise_distance_scores, nullptr), "d2h");
+    check(pf_stream_synchronize(im.device, nullptr), "sync");
+}
+
+// The encrypted form of preciseSearch.  Candidate rows are packed 64 to a plaintext polynomial (pf_pack_rows), brought
+// to NTT form and multiplied into the query ciphertext: ENC_POLYS_PER_QUERY = ceil(COARSE_PROBE * 128 / N) = 4
+// ciphertext x plaintext products per query, one fused launch for all of them.
+void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &ids,
+                                    uint64_t *result_ct_device) const {
+    const Impl &im = *m_Impl;
+    std::lock_guard<std::mutex> g(im.lock);
+    im.require_ready();
+    if (!query_ct_device || !result_ct_device) throw std::invalid_argument("preciseSearchEncrypted: null device pointer");
+    constexpr size_t polys = static_cast<size_t>(NQUERY) * ENC_POLYS_PER_QUERY;
+    std::vector<int64_t> padded(polys * ENC_ROWS_PER_POLY, -1);                 // -1: zero row
+    for (size_t q = 0; q < static_cast<size_t>(NQUERY); ++q)
+        for (size_t j = 0; j < static_cast<size_t>(COARSE_PROBE); ++j) padded[q * ENC_POLYS_PER_QUERY * ENC_ROWS_PER_POLY + j] = ids[q][j];
+    im.d_ids.reserve(im.device, padded.size() * 8);
+    im.d_pt.reserve(im.device, polys * ENC_LIMBS * ENC_RING_DEGREE * 8);
+    uint64_t *pt = static_cast<uint64_t *>(im.d_pt.ptr);
+    check(pf_memcpy_h2d(im.device, im.d_ids.ptr, padded.data(), padded.size() * 8, nullptr), "h2d");
+    check(pf_pack_rows(im.ring, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, pt, nullptr), "pf_pack_rows");
+    check(pf_ntt_forward(im.ring, pt, polys * ENC_LIMBS, nullptr), "pf_ntt_forward");
+    check(pf_ct_pt_mul_fanout(im.ring, query_ct_device, pt, result_ct_device, polys, ENC_POLYS_PER_QUERY, 0, nullptr), "pf_ct_pt_mul_fanout");
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }
 

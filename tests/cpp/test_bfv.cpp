@@ -1,0 +1,142 @@
+// test_bfv.cpp -- the client-side BFV library (include/client/bfv.h) and the encrypted precise search of the server
+// (Server::preciseSearchEncrypted) on a real MI355X: encrypt -> server -> decrypt must reproduce the plaintext
+// protocol's numbers exactly, with noise budget to spare.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/client/bfv.h"
+#include "../../include/prefhetch_hip.h"
+#include "../../include/server/server_lib.h"
+
+static int fails = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++fails; } } while (0)
+
+int main() {
+    // ---- 1. scheme round trips at three parameter sets ------------------------------------------------------
+    struct Case { uint32_t N; uint64_t t; };
+    for (const Case c : {Case{1024, 257}, Case{4096, 65537}, Case{8192, (1ull << 25) + 0x8001 /* any t coprime to the moduli */}}) {
+        bfv::Context ctx(bfv::Params::seal_default(c.N, c.t));
+        bfv::KeyGenerator keygen(ctx, bfv::seeded_random(1000 + c.N));
+        bfv::PublicKey pk = keygen.create_public_key();
+        bfv::Encryptor enc(ctx, pk, bfv::seeded_random(2000 + c.N));
+        bfv::Decryptor dec(ctx, keygen.secret_key());
+        const size_t count = 3;
+        std::vector<uint64_t> plain(count * c.N), back;
+        std::mt19937_64 rng(c.N);
+        for (auto &v : plain) v = rng() % c.t;
+        for (size_t i = 0; i < c.N; ++i) plain[i] = 0;                            // an all-zero plaintext
+        for (size_t i = 0; i < c.N; ++i) plain[c.N + i] = c.t - 1;                // the largest coefficients
+        bfv::Ciphertexts ct;
+        enc.encrypt(plain.data(), count, ct);
+        dec.decrypt(ct, back);
+        EXPECT(back == plain);
+        const int budget = dec.invariant_noise_budget(ct, 2);
+        std::printf("N=%u, %zu limb(s), log2 Q = %d, t = %llu: fresh noise budget %d bits\n", c.N, ctx.L(), ctx.total_modulus_bits(),
+                    (unsigned long long)c.t, budget);
+        EXPECT(budget > 0 && budget < ctx.total_modulus_bits());
+        // two encryptions of the same message differ (fresh randomness), the wrong key does not decrypt
+        bfv::Ciphertexts ct2;
+        enc.encrypt(plain.data(), 1, ct2);
+        std::vector<uint64_t> a(2 * ctx.L() * c.N), b(a.size());
+        ct.data.download(a.data(), a.size());
+        ct2.data.download(b.data(), b.size());
+        EXPECT(a != b);
+        bfv::KeyGenerator other(ctx, bfv::seeded_random(77));
+        bfv::Decryptor wrong(ctx, other.secret_key());
+        std::vector<uint64_t> junk;
+        wrong.decrypt(ct, junk);
+        EXPECT(junk != plain);
+        EXPECT(wrong.invariant_noise_budget(ct, 1) == 0);
+        // homomorphic addition through the C ABI: Dec(ct_0 + ct_2) = m_0 + m_2 mod t
+        bfv::Ciphertexts sum;
+        sum.count = 1;
+        sum.data = bfv::DeviceWords(0, 2 * ctx.L() * c.N);
+        const size_t per = 2 * ctx.L() * c.N;
+        EXPECT(pf_poly_add(ctx.ring(), ct.data.ptr(), ct.data.ptr() + 2 * per, sum.data.ptr(), 2 * ctx.L(), nullptr) == PF_OK);
+        std::vector<uint64_t> s;
+        dec.decrypt(sum, s);
+        bool ok = true;
+        for (size_t i = 0; i < c.N; ++i) ok = ok && s[i] == (plain[i] + plain[2 * c.N + i]) % c.t;
+        EXPECT(ok);
+    }
+
+    // ---- 2. the encrypted precise search against the plaintext one ------------------------------------------
+    {
+        std::mt19937 rng(5);
+        std::vector<float> base(static_cast<size_t>(NBASE) * 128);
+        for (auto &v : base) v = static_cast<float>(rng() % 256);
+        auto srv = Server::getInstance();
+        srv->init_from_memory(base.data(), NBASE);
+        std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> query;
+        for (auto &q : query) for (auto &v : q) v = static_cast<float>(rng() % 256);
+        std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> ids;
+        for (auto &row : ids) for (auto &v : row) v = rng() % NBASE;
+        ids[1][7] = ids[1][8];                                                      // a repeated candidate
+        std::array<std::array<float, COARSE_PROBE>, NQUERY> plain_dist;
+        srv->preciseSearch(query, ids, plain_dist);
+
+        // client: t must exceed twice the largest inner product, 128 * 255^2 = 8 323 200
+        const uint64_t t = (1ull << 25) + 0x8001;
+        bfv::Context ctx(bfv::Params::seal_default(Server::ENC_RING_DEGREE, t));
+        bfv::KeyGenerator keygen(ctx, bfv::seeded_random(42));
+        bfv::PublicKey pk = keygen.create_public_key();
+        bfv::Encryptor enc(ctx, pk, bfv::seeded_random(43));
+        bfv::Decryptor dec(ctx, keygen.secret_key());
+        const size_t N = ctx.N(), L = ctx.L();
+        std::vector<uint64_t> qplain(static_cast<size_t>(NQUERY) * N);
+        for (size_t i = 0; i < static_cast<size_t>(NQUERY); ++i) bfv::encode_query(query[i].data(), 128, (uint32_t)N, t, qplain.data() + i * N);
+        bfv::Ciphertexts qct;
+        enc.encrypt(qplain.data(), NQUERY, qct);
+        const int fresh = dec.invariant_noise_budget(qct, 0);
+
+        // server: sees ciphertexts and candidate ids only
+        bfv::Ciphertexts rct;
+        rct.count = static_cast<size_t>(NQUERY) * Server::ENC_POLYS_PER_QUERY;
+        rct.data = bfv::DeviceWords(0, rct.count * 2 * L * N);
+        srv->preciseSearchEncrypted(qct.data.ptr(), ids, rct.data.ptr());
+        Timer timer;                                                                 // second call: workspace and tables are warm
+        timer.StartTimer();
+        srv->preciseSearchEncrypted(qct.data.ptr(), ids, rct.data.ptr());
+        timer.StopTimer();
+        long long us = 0, ms = 0;
+        timer.getDuration(us, ms);
+        std::printf("Server::preciseSearchEncrypted: %lld us for %lld queries x %u ciphertext x plaintext products (pack + NTT + fused product, synchronous)\n",
+                    us, (long long)NQUERY, Server::ENC_POLYS_PER_QUERY);
+
+        // client: decrypt, decode, finish the distances with its own ||q||^2 and the row norms
+        std::vector<uint64_t> rplain;
+        dec.decrypt(rct, rplain);
+        const int after = dec.invariant_noise_budget(rct, 0);
+        std::printf("encrypted precise search: N=8192, 4 limbs, t=%llu: noise budget fresh %d bits, after ct x pt %d bits\n",
+                    (unsigned long long)t, fresh, after);
+        EXPECT(fresh > after && after > 60);
+        bool all_equal = true;
+        for (size_t i = 0; i < static_cast<size_t>(NQUERY); ++i) {
+            double qn = 0;
+            for (float v : query[i]) qn += double(v) * v;
+            for (size_t b = 0; b < Server::ENC_POLYS_PER_QUERY; ++b) {
+                int64_t ip[Server::ENC_ROWS_PER_POLY];
+                bfv::decode_inner_products(rplain.data() + (i * Server::ENC_POLYS_PER_QUERY + b) * N, 128, Server::ENC_ROWS_PER_POLY, t, ip);
+                for (size_t j = 0; j < Server::ENC_ROWS_PER_POLY; ++j) {
+                    const size_t cand = b * Server::ENC_ROWS_PER_POLY + j;
+                    if (cand >= static_cast<size_t>(COARSE_PROBE)) { all_equal = all_equal && ip[j] == 0; continue; }   // padding rows
+                    const float *row = base.data() + ids[i][cand] * 128;
+                    long long exact = 0;
+                    double xn = 0;
+                    for (int k = 0; k < 128; ++k) { exact += (long long)query[i][k] * (long long)row[k]; xn += double(row[k]) * row[k]; }
+                    all_equal = all_equal && ip[j] == exact;
+                    const double dist = qn - 2.0 * double(ip[j]) + xn;                // integers below 2^24: exact in fp32 too
+                    all_equal = all_equal && static_cast<float>(dist) == plain_dist[i][cand];
+                }
+            }
+        }
+        EXPECT(all_equal);
+    }
+    if (fails) std::printf("test_bfv: %d FAILURES\n", fails);
+    else std::printf("test_bfv: OK\n");
+    return fails ? 1 : 0;
+}

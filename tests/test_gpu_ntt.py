@@ -260,3 +260,28 @@ def test_errors_are_statuses(pf):
     c.ntt_forward_(empty)                                  # empty batch is a no-op
     with pytest.raises(ValueError):
         c.ntt_forward_(torch.zeros(1000, dtype=torch.int64, device=_dev()))
+
+
+@pytest.mark.parametrize("N,qs,fanout,B", [(1024, oracle.BFV_DEFAULT[1024], 3, 7), (8192, oracle.BFV_DEFAULT[8192][:4], 4, 20),
+                                           (4096, oracle.BFV_DEFAULT[4096][:2], 5, 5)])
+def test_ct_pt_mul_fanout(pf, N, qs, fanout, B):
+    """out[b] = ct[b // fanout] x pt[b]: the shape of the encrypted precise search (one query ciphertext against several
+    packed plaintext blocks), plain and accumulating, against the oracle's per-pair product."""
+    L = len(qs)
+    rng = np.random.default_rng(N + fanout)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    n_ct = -(-B // fanout)
+    ct = np.stack([np.stack([rng.integers(0, q, (2, N), dtype=np.uint64) for q in qs], axis=1) for _ in range(n_ct)])   # [n_ct][2][L][N]
+    pt = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(B)])                     # [B][L][N]
+    exp = o.ct_pt_mul(ct[np.arange(B) // fanout], pt)
+    d_ct, d_pt = pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev())
+    got = c.ct_pt_mul_fanout(d_ct, d_pt, fanout)
+    assert (pf.to_host_u64(got) == exp).all()
+    acc0 = np.stack([np.stack([rng.integers(0, q, (2, N), dtype=np.uint64) for q in qs], axis=1) for _ in range(B)])
+    d_acc = pf.to_device_u64(acc0, _dev())
+    c.ct_pt_mul_fanout(d_ct, d_pt, fanout, out=d_acc, flags=1)
+    exp_acc = o.ct_pt_mul(ct[np.arange(B) // fanout], pt, 1, acc=acc0)
+    assert (pf.to_host_u64(d_acc) == exp_acc).all()
+    with pytest.raises(ValueError):
+        c.ct_pt_mul_fanout(d_ct, d_pt, 0)

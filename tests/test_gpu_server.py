@@ -16,3 +16,12 @@ def test_server_class_reference_shapes(mode):
     assert os.path.exists(BIN), "tests/cpp/test_server missing: run __graft_entry__.build()"
     r = subprocess.run([BIN] + ([mode] if mode == "gaussian" else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "test_server: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_client_bfv_and_encrypted_precise_search():
+    """bfv:: key generation / encryption / decryption / noise budget over the C ABI, and Server::preciseSearchEncrypted
+    against the plaintext preciseSearch (exact equality of every distance)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_bfv")
+    assert os.path.exists(exe), "tests/cpp/test_bfv missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "test_bfv: OK" in r.stdout, r.stdout + r.stderr
