@@ -35,8 +35,10 @@ struct Params {
     uint32_t N = 0;                               // ring degree (1024 .. 32768)
     std::vector<uint64_t> moduli;                 // ciphertext primes q_0 .. q_{L-1}, each = 1 mod 2N
     uint64_t t = 0;                               // plaintext modulus, 2 <= t < 2^60, coprime to every q_l
+    uint64_t special_prime = 0;                   // key-switching prime P (0: no key switching), = 1 mod 2N
     int device = 0;
-    // SEAL CoeffModulus::BFVDefault(N) without its last (key-switching) prime: the data level of a fresh ciphertext
+    // SEAL CoeffModulus::BFVDefault(N): all primes but the last are the data level of a fresh ciphertext, the last is
+    // the key-switching prime (N = 1024 and 2048 have a single prime: no key switching, as in SEAL)
     static Params seal_default(uint32_t N, uint64_t t, int device = 0);
 };
 
@@ -70,6 +72,7 @@ class Context {
     size_t L() const { return m_Params.moduli.size(); }
     uint64_t t() const { return m_Params.t; }
     pf_ctx *ring() const { return m_Ring; }
+    pf_ctx *key_ring() const { return m_KeyRing; }   // data primes + special prime (nullptr without one)
     int total_modulus_bits() const;               // bit length of Q
 
     // exact host arithmetic on one coefficient given its residues mod q_0 .. q_{L-1}
@@ -80,13 +83,20 @@ class Context {
   private:
     struct Big;
     Params m_Params;
-    pf_ctx *m_Ring = nullptr;
+    pf_ctx *m_Ring = nullptr, *m_KeyRing = nullptr;
     std::unique_ptr<Big> m_Big;
 };
 
 struct SecretKey {
     std::vector<int8_t> coeff;                    // ternary, host copy
     DeviceWords ntt;                              // [L][N], NTT form
+    DeviceWords ntt_key;                          // [L+1][N], NTT form over the key moduli (with a special prime only)
+};
+// A key-switching key in the layout pf_key_switch takes: [D][2][D+1][N], NTT form over the key moduli; digit I is an
+// encryption under s of P * s' restricted to modulus I (SEAL KSwitchKeys / GaloisKeys entry).
+struct SwitchKey {
+    DeviceWords ksk;
+    uint32_t galois_elt = 0;                      // for Galois keys: the automorphism this key undoes
 };
 struct PublicKey {
     DeviceWords coeffs;                           // [2][L][N], COEFFICIENT form (the input pf_ct_pt_mul expects)
@@ -101,6 +111,10 @@ class KeyGenerator {
     KeyGenerator(const Context &ctx, ByteSource rng = system_random());
     const SecretKey &secret_key() const { return m_Secret; }
     PublicKey create_public_key();
+    // key that switches a ciphertext component multiplying s'(X) back to s(X); s' given by its small coefficients
+    SwitchKey create_switch_key(const std::vector<int8_t> &new_secret_coeff);
+    // Galois key of X -> X^galois_elt (galois_elt odd, < 2N): s' = s(X^galois_elt)
+    SwitchKey create_galois_key(uint32_t galois_elt);
 
   private:
     const Context &m_Ctx;
@@ -133,6 +147,13 @@ class Decryptor {
     const Context &m_Ctx;
     const SecretKey &m_Sk;
 };
+
+// Server-side use of a Galois key, here so that the key-switching path can be exercised on real ciphertexts:
+// out = Enc(m(X^g)) from in = Enc(m(X)): apply X -> X^g to both components (pf_apply_galois), then switch the second
+// one from s(X^g) back to s (pf_key_switch).  SEAL: Evaluator::apply_galois.
+void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &galois_key, Ciphertexts &out);
+// the plaintext side of the same map: m(X) -> m(X^g) mod (X^N + 1, t)
+void apply_galois_plain(const uint64_t *plain, uint32_t N, uint64_t t, uint32_t galois_elt, uint64_t *out);
 
 // ---- encoding of the encrypted precise search (pairs with pf_pack_rows on the server) --------------------------
 // query q[0..d) (integers after rounding) -> plaintext polynomial sum_i q_i X^i, coefficients mod t

@@ -97,6 +97,13 @@ enum { PF_CTPT_ACCUMULATE = 1, PF_CTPT_IN_NTT = 2, PF_CTPT_OUT_NTT = 4 };
 pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, size_t pt_count,
                        uint64_t *out, size_t B, int flags, pf_stream stream);
 
+/* util::GaloisTool::apply_galois (coefficient form), the permutation half of Evaluator::apply_galois_inplace /
+ * rotate_rows / rotate_columns: out(X) = in(X^galois_elt) mod (X^N + 1), i.e. coefficient i moves to position
+ * i * galois_elt mod 2N, negated when that position is >= N.  galois_elt odd, in [1, 2N).  out must not alias in.
+ * Follow with pf_key_switch (target = the permuted c1, key = the Galois key of galois_elt) to return to the original
+ * secret key.  HBM-bound, 16 bytes per coefficient. */
+pf_status pf_apply_galois(pf_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n_limb_polys, uint32_t galois_elt, pf_stream stream);
+
 /* Evaluator::switch_key_inplace (what relinearize_inplace / rotate_rows / apply_galois run), BFV form: the
  * polynomial `target` (coefficient form) is re-encrypted under the secret key through the key-switching key and
  * ADDED into both components of `ct`.  `ctx` must hold the KEY moduli: the data primes q_0..q_{D-1} followed by

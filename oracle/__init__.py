@@ -172,6 +172,24 @@ def gather_rows(base, ids):
     return out
 
 
+def apply_galois(polys, galois_elt, moduli):
+    """out(X) = in(X^g) mod (X^N + 1) per limb-polynomial (SEAL util::GaloisTool::apply_galois, coefficient form;
+    restated from the definition): polys [..., L, N] canonical residues, limb = second-to-last axis."""
+    polys = np.asarray(polys, np.uint64)
+    N = polys.shape[-1]
+    flat = polys.reshape(-1, len(moduli), N)
+    out = np.zeros_like(flat)
+    i = np.arange(N, dtype=np.int64)
+    j = (i * int(galois_elt)) % (2 * N)
+    dst = j % N
+    neg = j >= N
+    for l, q in enumerate(moduli):
+        v = flat[:, l, :]
+        w = np.where(neg[None, :] & (v != 0), np.uint64(q) - v, v)
+        out[:, l, dst] = w
+    return out.reshape(polys.shape)
+
+
 def pack_rows(base, ids, N, moduli):
     """Plaintext packing of the encrypted precise search (the build's own encoding; the reference leaves this step as
     TODOs, include/client/client_lib.h:14,28-30): p(X) = sum_j sum_i x[ids[p][j]][i] X^(d*j - i) mod (X^N + 1), values

@@ -142,6 +142,16 @@ class RnsContext:
         check(lib.pf_ct_pt_mul_fanout(self._h, pc, pp, po, B, int(fanout), int(flags), _stream(self.device)), "pf_ct_pt_mul_fanout")
         return out
 
+    def apply_galois(self, polys, galois_elt, out=None):
+        """out(X) = polys(X^galois_elt) mod (X^N + 1) on coefficient-form limb-polynomials [..., L, N]."""
+        if polys.numel() % (self.L * self.N):
+            raise ValueError("size is not a multiple of L*N")
+        if out is None:
+            out = torch.empty_like(polys)
+        pi, po = _req(polys, torch.int64, self.device_index, "polys"), _req(out, torch.int64, self.device_index, "out")
+        check(lib.pf_apply_galois(self._h, pi, po, polys.numel() // self.N, int(galois_elt), _stream(self.device)), "pf_apply_galois")
+        return out
+
     def pack_rows(self, flat, ids, out=None):
         """Plaintext polynomials of the encrypted precise search: ids [n_polys, rows_per_poly] (int64, device) rows of
         the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_)."""

@@ -196,12 +196,18 @@ ByteSource seeded_random(uint64_t seed) {
 Params Params::seal_default(uint32_t N, uint64_t t, int device) {
     Params p;
     p.N = N; p.t = t; p.device = device;
-    switch (N) {                                   // SEAL CoeffModulus::BFVDefault(N) minus the key-switching prime
+    switch (N) {                                   // SEAL CoeffModulus::BFVDefault(N); the last prime is the special one
         case 1024: p.moduli = {0x7E00001}; break;
         case 2048: p.moduli = {0x3FFFFFFF000001}; break;
-        case 4096: p.moduli = {0xFFFFEE001, 0xFFFFC4001}; break;
-        case 8192: p.moduli = {0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001}; break;
-        default: throw std::invalid_argument("bfv::Params::seal_default: N must be 1024, 2048, 4096 or 8192");
+        case 4096: p.moduli = {0xFFFFEE001, 0xFFFFC4001}; p.special_prime = 0x1FFFFE0001; break;
+        case 8192: p.moduli = {0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001}; p.special_prime = 0xFFFFFEBC001; break;
+        case 32768:
+            p.moduli = {0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0x7FFFFFFFBD0001, 0x7FFFFFFFBA0001, 0x7FFFFFFFAA0001, 0x7FFFFFFFA50001,
+                        0x7FFFFFFF9F0001, 0x7FFFFFFF7E0001, 0x7FFFFFFF770001, 0x7FFFFFFF380001, 0x7FFFFFFF330001, 0x7FFFFFFF2D0001,
+                        0x7FFFFFFF170001, 0x7FFFFFFF150001, 0x7FFFFFFEF00001};
+            p.special_prime = 0xFFFFFFFFF70001;
+            break;
+        default: throw std::invalid_argument("bfv::Params::seal_default: N must be 1024, 2048, 4096, 8192 or 32768");
     }
     return p;
 }
@@ -248,6 +254,11 @@ Context::Context(const Params &params) : m_Params(params), m_Big(new Big) {
     for (uint64_t m : q)
         if (m_Params.t % m == 0 || std::gcd(m_Params.t, m) != 1) throw std::invalid_argument("bfv::Context: t must be coprime to the moduli");
     check(pf_ctx_create(&m_Ring, m_Params.device, m_Params.N, (uint32_t)q.size(), q.data()), "pf_ctx_create");
+    if (m_Params.special_prime) {
+        std::vector<uint64_t> key_moduli = q;
+        key_moduli.push_back(m_Params.special_prime);
+        check(pf_ctx_create(&m_KeyRing, m_Params.device, m_Params.N, (uint32_t)key_moduli.size(), key_moduli.data()), "pf_ctx_create(key moduli)");
+    }
     Big &b = *m_Big;
     b.Q = {1};
     b.r_t = 1 % m_Params.t;
@@ -268,7 +279,10 @@ Context::Context(const Params &params) : m_Params(params), m_Big(new Big) {
     }
 }
 
-Context::~Context() { if (m_Ring) pf_ctx_destroy(m_Ring); }
+Context::~Context() {
+    if (m_Ring) pf_ctx_destroy(m_Ring);
+    if (m_KeyRing) pf_ctx_destroy(m_KeyRing);
+}
 
 int Context::total_modulus_bits() const { return bit_length(m_Big->Q); }
 
@@ -334,7 +348,72 @@ KeyGenerator::KeyGenerator(const Context &ctx, ByteSource rng) : m_Ctx(ctx), m_R
     m_Secret.ntt = DeviceWords(ctx.params().device, L * N);
     m_Secret.ntt.upload(res.data(), L * N);
     check(pf_ntt_forward(ctx.ring(), m_Secret.ntt.ptr(), L, nullptr), "pf_ntt_forward");
+    if (ctx.key_ring()) {
+        std::vector<uint64_t> key_moduli = ctx.params().moduli;
+        key_moduli.push_back(ctx.params().special_prime);
+        std::vector<uint64_t> kres((L + 1) * N);
+        to_residues(m_Secret.coeff, key_moduli, kres.data());
+        m_Secret.ntt_key = DeviceWords(ctx.params().device, (L + 1) * N);
+        m_Secret.ntt_key.upload(kres.data(), (L + 1) * N);
+        check(pf_ntt_forward(ctx.key_ring(), m_Secret.ntt_key.ptr(), L + 1, nullptr), "pf_ntt_forward");
+    }
     check(pf_stream_synchronize(ctx.params().device, nullptr), "sync");
+}
+
+// Digit I of the key: (-(a_I s + e_I) + [J == I] (P mod q_I) s', a_I) over the key moduli J, NTT form -- the published
+// RNS key-switching key with one special prime (SEAL KeyGenerator::generate_one_kswitch_key).
+SwitchKey KeyGenerator::create_switch_key(const std::vector<int8_t> &new_secret) {
+    if (!m_Ctx.key_ring()) throw std::runtime_error("bfv: these parameters have no special prime: key switching is not available");
+    const size_t N = m_Ctx.N(), D = m_Ctx.L(), Kn = D + 1;
+    if (new_secret.size() != N) throw std::invalid_argument("bfv: new secret must have N coefficients");
+    const int dev = m_Ctx.params().device;
+    std::vector<uint64_t> key_moduli = m_Ctx.params().moduli;
+    key_moduli.push_back(m_Ctx.params().special_prime);
+    const uint64_t P = m_Ctx.params().special_prime;
+    Buffered r(m_Rng);
+    SwitchKey out;
+    out.ksk = DeviceWords(dev, D * 2 * Kn * N);
+    // NTT(s') over the key moduli, on the host for the per-digit correction
+    std::vector<uint64_t> sp(Kn * N);
+    to_residues(new_secret, key_moduli, sp.data());
+    DeviceWords d_sp(dev, Kn * N), d_e(dev, Kn * N);
+    d_sp.upload(sp.data(), Kn * N);
+    check(pf_ntt_forward(m_Ctx.key_ring(), d_sp.ptr(), Kn, nullptr), "pf_ntt_forward");
+    d_sp.download(sp.data(), Kn * N);
+    std::vector<uint64_t> a(Kn * N), e_res(Kn * N), row(N);
+    std::vector<int8_t> e(N);
+    for (size_t I = 0; I < D; ++I) {
+        uint64_t *k0 = out.ksk.ptr() + (I * 2 + 0) * Kn * N, *k1 = out.ksk.ptr() + (I * 2 + 1) * Kn * N;
+        for (size_t J = 0; J < Kn; ++J) sample_uniform(r, key_moduli[J], a.data() + J * N, N);      // a_I, NTT form
+        sample_error(r, e);
+        to_residues(e, key_moduli, e_res.data());
+        out.ksk.upload(a.data(), Kn * N, (I * 2 + 1) * Kn * N);
+        d_e.upload(e_res.data(), Kn * N);
+        check(pf_ntt_forward(m_Ctx.key_ring(), d_e.ptr(), Kn, nullptr), "pf_ntt_forward");
+        check(pf_dyadic_mul(m_Ctx.key_ring(), k1, m_Secret.ntt_key.ptr(), k0, Kn, nullptr), "pf_dyadic_mul");      // a s
+        check(pf_poly_add(m_Ctx.key_ring(), k0, d_e.ptr(), k0, Kn, nullptr), "pf_poly_add");                       // + e
+        check(pf_poly_negate(m_Ctx.key_ring(), k0, k0, Kn, nullptr), "pf_poly_negate");
+        check(pf_stream_synchronize(dev, nullptr), "sync");
+        // + (P mod q_I) * s' on modulus I only
+        const uint64_t q = key_moduli[I], f = P % q;
+        out.ksk.download(row.data(), N, (I * 2 + 0) * Kn * N + I * N);
+        for (size_t n = 0; n < N; ++n) row[n] = (row[n] + mulmod(f, sp[I * N + n], q)) % q;
+        out.ksk.upload(row.data(), N, (I * 2 + 0) * Kn * N + I * N);
+    }
+    return out;
+}
+
+SwitchKey KeyGenerator::create_galois_key(uint32_t g) {
+    const size_t N = m_Ctx.N();
+    if (!(g & 1) || g >= 2 * N) throw std::invalid_argument("bfv: galois_elt must be odd and below 2N");
+    std::vector<int8_t> sg(N);
+    for (size_t i = 0; i < N; ++i) {                                               // s(X^g)
+        const size_t j = (i * (size_t)g) % (2 * N);
+        sg[j % N] = j >= N ? (int8_t)-m_Secret.coeff[i] : m_Secret.coeff[i];
+    }
+    SwitchKey k = create_switch_key(sg);
+    k.galois_elt = g;
+    return k;
 }
 
 PublicKey KeyGenerator::create_public_key() {
@@ -459,6 +538,35 @@ int Decryptor::invariant_noise_budget(const Ciphertexts &ct, size_t index) {
     }
     const int budget = m_Ctx.total_modulus_bits() - worst - 1;
     return budget > 0 ? budget : 0;
+}
+
+// ---- Galois automorphism on ciphertexts ----------------------------------------------------------------------
+void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &key, Ciphertexts &out) {
+    if (!ctx.key_ring()) throw std::runtime_error("bfv: these parameters have no special prime: key switching is not available");
+    if (!key.galois_elt) throw std::invalid_argument("bfv::apply_galois: not a Galois key");
+    const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N;
+    const int dev = ctx.params().device;
+    out.count = in.count;
+    if (in.count == 0) return;
+    if (out.data.words() < in.count * per) out.data = DeviceWords(dev, in.count * per);
+    DeviceWords target(dev, in.count * L * N);
+    for (size_t i = 0; i < in.count; ++i) {
+        const uint64_t *c0 = in.data.ptr() + i * per, *c1 = c0 + L * N;
+        uint64_t *o0 = out.data.ptr() + i * per, *o1 = o0 + L * N, *tg = target.ptr() + i * L * N;
+        check(pf_apply_galois(ctx.ring(), c0, o0, L, key.galois_elt, nullptr), "pf_apply_galois");       // tau(c0)
+        check(pf_apply_galois(ctx.ring(), c1, tg, L, key.galois_elt, nullptr), "pf_apply_galois");       // tau(c1): the polynomial to switch
+        check(pf_poly_sub(ctx.ring(), tg, tg, o1, L, nullptr), "pf_poly_sub");                            // second component starts at zero
+    }
+    check(pf_key_switch(ctx.key_ring(), target.ptr(), key.ksk.ptr(), out.data.ptr(), in.count, nullptr), "pf_key_switch");
+    check(pf_stream_synchronize(dev, nullptr), "sync");
+}
+
+void apply_galois_plain(const uint64_t *plain, uint32_t N, uint64_t t, uint32_t g, uint64_t *out) {
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint64_t j = ((uint64_t)i * g) % (2ull * N);
+        const uint64_t v = plain[i] % t;
+        out[j % N] = (j >= N && v) ? t - v : v;
+    }
 }
 
 // ---- encoding of the encrypted precise search ----------------------------------------------------------------

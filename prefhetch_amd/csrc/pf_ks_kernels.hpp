@@ -132,4 +132,23 @@ __global__ void __launch_bounds__(256) k_pack_rows(PackArgs p) {
     p.out[pl * N + c] = v >= 0 ? (uint64_t)v : q - (uint64_t)(-v);
 }
 
+// ---- Galois automorphism X -> X^g on coefficient-form polynomials (pf_apply_galois) ---------------------------
+// One thread per INPUT coefficient: reads are coalesced, writes follow the permutation (stride g: lanes hit distinct
+// 8-byte words of a few cache lines).  16 B of traffic per coefficient.
+struct GaloisArgs {
+    const LimbDev *limbs;
+    const uint64_t *in; uint64_t *out;
+    uint32_t L, logn, galois_elt;
+};
+
+__global__ void __launch_bounds__(256) k_apply_galois(GaloisArgs p) {
+    const uint32_t N = 1u << p.logn, per = N / 256;
+    const size_t poly = blockIdx.x / per;
+    const uint32_t i = (uint32_t)(blockIdx.x % per) * 256 + threadIdx.x;
+    const uint64_t q = p.limbs[poly % p.L].q;
+    const uint64_t v = p.in[poly * N + i];
+    const uint32_t j = (uint32_t)(((uint64_t)i * p.galois_elt) & (2u * N - 1));
+    p.out[poly * N + (j & (N - 1))] = (j >= N && v) ? q - v : v;
+}
+
 }  // namespace pf

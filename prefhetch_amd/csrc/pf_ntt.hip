@@ -289,6 +289,21 @@ pf_status pf_pack_rows(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t
     return PF_OK;
 }
 
+pf_status pf_apply_galois(pf_ctx *c, const uint64_t *in, uint64_t *out, size_t n, uint32_t galois_elt, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (n == 0) return PF_OK;
+    if (!in || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (in == out) return fail(PF_ERR_INVALID_ARG, "pf_apply_galois is not an in-place operation");
+    if (!(galois_elt & 1) || galois_elt >= 2 * c->N) return fail(PF_ERR_INVALID_ARG, "galois_elt must be odd and below 2N");
+    const size_t blocks = n * (c->N / 256);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
+    PF_GUARD(c->device);
+    GaloisArgs a{c->d_limbs, in, out, c->L, c->logn, galois_elt};
+    hipLaunchKernelGGL(k_apply_galois, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream) {
     if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
     if (B == 0) return PF_OK;

@@ -64,6 +64,43 @@ int main() {
         EXPECT(ok);
     }
 
+    // ---- 1b. key switching on real ciphertexts: Dec(apply_galois(Enc(m))) = m(X^g), at SEAL's default parameter sets
+    // with a special prime, N = 32768 / 15 + 1 primes (BASELINE config 5) included --------------------------------
+    for (const Case c : {Case{4096, 65537}, Case{8192, 65537}, Case{32768, 65537}}) {
+        bfv::Context ctx(bfv::Params::seal_default(c.N, c.t));
+        bfv::KeyGenerator keygen(ctx, bfv::seeded_random(3000 + c.N));
+        bfv::PublicKey pk = keygen.create_public_key();
+        bfv::Encryptor enc(ctx, pk, bfv::seeded_random(4000 + c.N));
+        bfv::Decryptor dec(ctx, keygen.secret_key());
+        std::vector<uint64_t> plain(2 * c.N), back, expect(c.N);
+        std::mt19937_64 rng(c.N + 1);
+        for (auto &v : plain) v = rng() % c.t;
+        bfv::Ciphertexts ct, rot, rot2;
+        enc.encrypt(plain.data(), 2, ct);
+        const int fresh = dec.invariant_noise_budget(ct, 0);
+        int after = 0;
+        for (const uint32_t g : {3u, 2 * c.N - 1}) {                                   // a row rotation step and the column swap of SEAL's batching
+            bfv::SwitchKey gk = keygen.create_galois_key(g);
+            bfv::apply_galois(ctx, ct, gk, rot);
+            dec.decrypt(rot, back);
+            bool ok = true;
+            for (size_t i = 0; i < 2; ++i) {
+                bfv::apply_galois_plain(plain.data() + i * c.N, c.N, c.t, g, expect.data());
+                ok = ok && std::memcmp(expect.data(), back.data() + i * c.N, c.N * 8) == 0;
+            }
+            EXPECT(ok);
+            after = dec.invariant_noise_budget(rot, 1);
+            EXPECT(after > 0 && after <= fresh);
+            if (g == 3) {                                                              // twice: X -> X^9
+                bfv::apply_galois(ctx, rot, gk, rot2);
+                dec.decrypt(rot2, back);
+                bfv::apply_galois_plain(plain.data(), c.N, c.t, 9, expect.data());
+                EXPECT(std::memcmp(expect.data(), back.data(), c.N * 8) == 0);
+            }
+        }
+        std::printf("N=%u, %zu + 1 primes: Galois automorphism + key switch decrypts to m(X^g); noise budget %d -> %d bits\n", c.N, ctx.L(), fresh, after);
+    }
+
     // ---- 2. the encrypted precise search against the plaintext one ------------------------------------------
     {
         std::mt19937 rng(5);

@@ -285,3 +285,27 @@ def test_ct_pt_mul_fanout(pf, N, qs, fanout, B):
     assert (pf.to_host_u64(d_acc) == exp_acc).all()
     with pytest.raises(ValueError):
         c.ct_pt_mul_fanout(d_ct, d_pt, 0)
+
+
+@pytest.mark.parametrize("N,qs", [(1024, oracle.BFV_DEFAULT[1024]), (8192, oracle.BFV_DEFAULT[8192][:4]), (32768, oracle.BFV_DEFAULT[32768][:3])])
+def test_apply_galois(pf, N, qs):
+    """X -> X^g on coefficient-form polynomials against the definition, plus the group law tau_g(tau_h(a)) = tau_{gh}(a)
+    and tau_g(a) * tau_g(b) = tau_g(a * b) through the NTT product."""
+    L = len(qs)
+    rng = np.random.default_rng(N)
+    a = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 3, 0)])      # [4][L][N]
+    c = _ctx(pf, N, qs)
+    d = pf.to_device_u64(a, _dev())
+    for g in (3, 9, 2 * N - 1, 5, 1):
+        got = pf.to_host_u64(c.apply_galois(d, g))
+        assert (got == oracle.apply_galois(a, g, qs)).all(), g
+    gh = (3 * 5) % (2 * N)
+    assert (pf.to_host_u64(c.apply_galois(c.apply_galois(d, 5), 3)) == oracle.apply_galois(a, gh, qs)).all()
+    o = oracle.Oracle(N, qs)
+    prod = o.ntt_inverse(o.dyadic_mul(o.ntt_forward(a[0]), o.ntt_forward(a[3])))
+    ta, tb = oracle.apply_galois(a[0], 3, qs), oracle.apply_galois(a[3], 3, qs)
+    assert (o.ntt_inverse(o.dyadic_mul(o.ntt_forward(ta), o.ntt_forward(tb))) == oracle.apply_galois(prod, 3, qs)).all()
+    with pytest.raises(pf.PfError):
+        c.apply_galois(d, 4)
+    with pytest.raises(pf.PfError):
+        c.apply_galois(d, 3, out=d)
