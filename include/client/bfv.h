@@ -148,6 +148,27 @@ class Decryptor {
     const SecretKey &m_Sk;
 };
 
+// SEAL's BatchEncoder, restated (batchencoder.cpp: slot i of the first row is the plaintext's value at psi_t^(3^i), slot
+// i of the second row its value at psi_t^(-3^i), psi_t the minimal primitive 2N-th root of unity mod t): N values mod
+// t <-> one plaintext polynomial, so that ciphertext addition / plaintext multiplication act slot-wise and the Galois
+// automorphism X -> X^3 rotates both rows left by one, X -> X^(2N-1) swaps the rows.  t must be a prime = 1 mod 2N.
+// The transforms run on the GPU through a one-modulus context over t.
+class BatchEncoder {
+  public:
+    explicit BatchEncoder(const Context &ctx);
+    ~BatchEncoder();
+    BatchEncoder(const BatchEncoder &) = delete;
+    BatchEncoder &operator=(const BatchEncoder &) = delete;
+    size_t slot_count() const { return m_IndexMap.size(); }
+    void encode(const uint64_t *values /* [N], each < t */, uint64_t *plain_out /* [N] */) const;
+    void decode(const uint64_t *plain /* [N] */, uint64_t *values_out /* [N] */) const;
+
+  private:
+    const Context &m_Ctx;
+    pf_ctx *m_PlainRing = nullptr;
+    std::vector<uint32_t> m_IndexMap;
+};
+
 // Server-side use of a Galois key, here so that the key-switching path can be exercised on real ciphertexts:
 // out = Enc(m(X^g)) from in = Enc(m(X)): apply X -> X^g to both components (pf_apply_galois), then switch the second
 // one from s(X^g) back to s (pf_key_switch).  SEAL: Evaluator::apply_galois.

@@ -540,6 +540,53 @@ int Decryptor::invariant_noise_budget(const Ciphertexts &ct, size_t index) {
     return budget > 0 ? budget : 0;
 }
 
+// ---- batching ------------------------------------------------------------------------------------------------
+BatchEncoder::BatchEncoder(const Context &ctx) : m_Ctx(ctx) {
+    const uint32_t N = ctx.N();
+    const uint64_t t = ctx.t();
+    check(pf_ctx_create(&m_PlainRing, ctx.params().device, N, 1, &t), "pf_ctx_create(plaintext modulus: must be a prime = 1 mod 2N)");
+    int logn = 0;
+    while ((1u << logn) < N) ++logn;
+    auto reverse_bits = [logn](uint32_t v) {
+        uint32_t r = 0;
+        for (int b = 0; b < logn; ++b) r |= ((v >> b) & 1u) << (logn - 1 - b);
+        return r;
+    };
+    m_IndexMap.resize(N);
+    const uint32_t row = N / 2, m = 2 * N;
+    uint64_t pos = 1;
+    for (uint32_t i = 0; i < row; ++i) {
+        m_IndexMap[i] = reverse_bits((uint32_t)((pos - 1) >> 1));
+        m_IndexMap[row | i] = reverse_bits((uint32_t)((m - pos - 1) >> 1));
+        pos = (pos * 3) & (m - 1);
+    }
+}
+
+BatchEncoder::~BatchEncoder() { if (m_PlainRing) pf_ctx_destroy(m_PlainRing); }
+
+void BatchEncoder::encode(const uint64_t *values, uint64_t *plain_out) const {
+    const size_t N = m_IndexMap.size();
+    std::vector<uint64_t> tmp(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (values[i] >= m_Ctx.t()) throw std::invalid_argument("bfv::BatchEncoder: value not below t");
+        tmp[m_IndexMap[i]] = values[i];
+    }
+    DeviceWords d(m_Ctx.params().device, N);
+    d.upload(tmp.data(), N);
+    check(pf_ntt_inverse(m_PlainRing, d.ptr(), 1, nullptr), "pf_ntt_inverse");
+    d.download(plain_out, N);
+}
+
+void BatchEncoder::decode(const uint64_t *plain, uint64_t *values_out) const {
+    const size_t N = m_IndexMap.size();
+    DeviceWords d(m_Ctx.params().device, N);
+    d.upload(plain, N);
+    check(pf_ntt_forward(m_PlainRing, d.ptr(), 1, nullptr), "pf_ntt_forward");
+    std::vector<uint64_t> tmp(N);
+    d.download(tmp.data(), N);
+    for (size_t i = 0; i < N; ++i) values_out[i] = tmp[m_IndexMap[i]];
+}
+
 // ---- Galois automorphism on ciphertexts ----------------------------------------------------------------------
 void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &key, Ciphertexts &out) {
     if (!ctx.key_ring()) throw std::runtime_error("bfv: these parameters have no special prime: key switching is not available");

@@ -98,6 +98,49 @@ int main() {
                 EXPECT(std::memcmp(expect.data(), back.data(), c.N * 8) == 0);
             }
         }
+        // batching: slot-wise semantics of plaintext multiplication and of the two generators of the Galois group
+        {
+            bfv::BatchEncoder be(ctx);
+            const size_t row = c.N / 2;
+            std::vector<uint64_t> va(c.N), vb(c.N), pa(c.N), pb(c.N), out(c.N), dec_plain;
+            for (auto &v : va) v = rng() % c.t;
+            for (auto &v : vb) v = rng() % 7;
+            be.encode(va.data(), pa.data());
+            be.encode(vb.data(), pb.data());
+            be.decode(pa.data(), out.data());
+            EXPECT(out == va);                                                          // decode . encode = id
+            bfv::Ciphertexts ca, cr;
+            enc.encrypt(pa.data(), 1, ca);
+            bfv::SwitchKey g3 = keygen.create_galois_key(3), gcol = keygen.create_galois_key(2 * c.N - 1);
+            bfv::apply_galois(ctx, ca, g3, cr);                                          // rotate_rows(1)
+            dec.decrypt(cr, dec_plain);
+            be.decode(dec_plain.data(), out.data());
+            bool ok = true;
+            for (size_t i = 0; i < row; ++i) ok = ok && out[i] == va[(i + 1) % row] && out[row + i] == va[row + (i + 1) % row];
+            EXPECT(ok);
+            bfv::apply_galois(ctx, ca, gcol, cr);                                        // rotate_columns
+            dec.decrypt(cr, dec_plain);
+            be.decode(dec_plain.data(), out.data());
+            ok = true;
+            for (size_t i = 0; i < row; ++i) ok = ok && out[i] == va[row + i] && out[row + i] == va[i];
+            EXPECT(ok);
+            // ciphertext x plaintext acts slot-wise: Dec(Enc(a) * b) decodes to a_i * b_i mod t
+            std::vector<uint64_t> pb_res(ctx.L() * c.N);
+            for (size_t l = 0; l < ctx.L(); ++l)
+                for (size_t i = 0; i < c.N; ++i) pb_res[l * c.N + i] = pb[i];           // b's coefficients are below t < q_l
+            bfv::DeviceWords d_pb(0, ctx.L() * c.N);
+            d_pb.upload(pb_res.data(), pb_res.size());
+            EXPECT(pf_ntt_forward(ctx.ring(), d_pb.ptr(), ctx.L(), nullptr) == PF_OK);
+            bfv::Ciphertexts prod;
+            prod.count = 1;
+            prod.data = bfv::DeviceWords(0, 2 * ctx.L() * c.N);
+            EXPECT(pf_ct_pt_mul(ctx.ring(), ca.data.ptr(), d_pb.ptr(), 1, prod.data.ptr(), 1, 0, nullptr) == PF_OK);
+            dec.decrypt(prod, dec_plain);
+            be.decode(dec_plain.data(), out.data());
+            ok = true;
+            for (size_t i = 0; i < c.N; ++i) ok = ok && out[i] == (unsigned __int128)va[i] * vb[i] % c.t;
+            EXPECT(ok);
+        }
         std::printf("N=%u, %zu + 1 primes: Galois automorphism + key switch decrypts to m(X^g); noise budget %d -> %d bits\n", c.N, ctx.L(), fresh, after);
     }
 
