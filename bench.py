@@ -217,6 +217,39 @@ def main():
         variants["gaussian_k100_ms"] = timed_search(flat_g, xq_g, 100)
         del flat_g, xq_g
 
+    # The encrypted precise search at batch size (SURVEY.md 8(d)'s protocol-level figure, measured rather
+    # than derived): per query ceil(COARSE_PROBE * 128 / N) = 4 plaintext blocks of 64 candidate rows -> pack, forward
+    # NTT of the plaintexts, ONE forward NTT of the query ciphertext, 4 fused dyadic + inverse-NTT products.
+    enc_round = None
+    if rank == 0 and world == 1:
+        fan, rows = 4, N_RING // DIM
+        ids = torch.full((B * fan, rows), -1, dtype=torch.int64, device=dev)
+        gi = torch.Generator(device=dev).manual_seed(SEED)
+        cand = torch.randint(0, args.nb, (B, TOPK), generator=gi, device=dev)
+        ids.view(B, fan * rows)[:, :TOPK] = cand
+        ptb = torch.empty((B * fan, LIMBS, N_RING), dtype=torch.int64, device=dev)
+        ctn = torch.empty_like(ct)
+        res = torch.empty((B * fan, 2, LIMBS, N_RING), dtype=torch.int64, device=dev)
+
+        def encrypted_round():
+            ctx.pack_rows(flat, ids, out=ptb)
+            ctx.ntt_forward_(ptb)
+            ctn.copy_(ct)
+            ctx.ntt_forward_(ctn)
+            ctx.ct_pt_mul_fanout(ctn, ptb, fan, out=res, flags=2)          # IN_NTT
+
+        encrypted_round()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            encrypted_round()
+        b.record()
+        torch.cuda.synchronize()
+        ms_enc = a.elapsed_time(b) / 5
+        enc_round = {"ms": ms_enc, "queries_per_s": B / (ms_enc * 1e-3), "ct_x_pt_per_query": fan, "candidates_per_query": TOPK,
+                     "note": "pack 64 rows per plaintext + NTT(pt) + one NTT(query ct) + fused dyadic / inverse NTT with ciphertext fan-out"}
+        del ids, ptb, ctn, res
+
     ms_a = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_b = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ms_c = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
@@ -262,6 +295,8 @@ def main():
         }
         if variants:
             res["prefilter_variants"] = variants
+        if enc_round:
+            res["encrypted_precise_search"] = enc_round
         if pcie:
             if "h2d_ms" in pcie:
                 pcie["queries_per_s_if_inputs_and_outputs_crossed_pcie"] = B / ((ms_per_step + pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)

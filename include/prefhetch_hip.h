@@ -56,6 +56,7 @@ pf_status pf_malloc(int device, void **dptr, size_t bytes);
 pf_status pf_free(int device, void *dptr);
 pf_status pf_memcpy_h2d(int device, void *dst, const void *src_host, size_t bytes, pf_stream stream);
 pf_status pf_memcpy_d2h(int device, void *dst_host, const void *src, size_t bytes, pf_stream stream);
+pf_status pf_memcpy_d2d(int device, void *dst, const void *src, size_t bytes, pf_stream stream);
 pf_status pf_stream_synchronize(int device, pf_stream stream);
 
 /* ---- RNS ring context ------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PREFHETCH_HIP_LIB") or os.path.join(_HERE, "lib", "li
 # every symbol include/prefhetch_hip.h declares
 SYMBOLS = [
     "pf_status_str", "pf_last_error", "pf_device_count",
-    "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_stream_synchronize",
+    "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_memcpy_d2d", "pf_stream_synchronize",
     "pf_ctx_create", "pf_ctx_destroy", "pf_ctx_info", "pf_ctx_force_u64",
     "pf_ntt_forward", "pf_ntt_inverse", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
     "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_key_switch", "pf_pack_rows",
@@ -44,6 +44,7 @@ def _load():
     lib.pf_free.argtypes = [i32, vp]
     lib.pf_memcpy_h2d.argtypes = [i32, vp, vp, sz, vp]
     lib.pf_memcpy_d2h.argtypes = [i32, vp, vp, sz, vp]
+    lib.pf_memcpy_d2d.argtypes = [i32, vp, vp, sz, vp]
     lib.pf_stream_synchronize.argtypes = [i32, vp]
     lib.pf_ctx_create.argtypes = [C.POINTER(vp), i32, u32, u32, C.POINTER(C.c_uint64)]
     lib.pf_ctx_destroy.argtypes = [vp]

@@ -126,6 +126,11 @@ pf_status pf_memcpy_d2h(int device, void *dst_host, const void *src, size_t byte
     PF_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
     return PF_OK;
 }
+pf_status pf_memcpy_d2d(int device, void *dst, const void *src, size_t bytes, pf_stream stream) {
+    PF_GUARD(device);
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return PF_OK;
+}
 pf_status pf_stream_synchronize(int device, pf_stream stream) {
     PF_GUARD(device);
     PF_HIP(hipStreamSynchronize(as_stream(stream)));
