@@ -80,17 +80,6 @@ Words sub(const Words &a, const Words &b) {          // a >= b
     trim(r);
     return r;
 }
-Words add(const Words &a, const Words &b) {
-    Words r(a.size() > b.size() ? a.size() : b.size());
-    uint64_t carry = 0;
-    for (size_t i = 0; i < r.size(); ++i) {
-        const u128 s = (u128)(i < a.size() ? a[i] : 0) + (i < b.size() ? b[i] : 0) + carry;
-        r[i] = (uint64_t)s;
-        carry = (uint64_t)(s >> 64);
-    }
-    if (carry) r.push_back(carry);
-    return r;
-}
 int bit_length(const Words &a) {
     for (size_t i = a.size(); i-- > 0;)
         if (a[i]) return (int)(i * 64 + 64 - __builtin_clzll(a[i]));
