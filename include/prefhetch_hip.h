@@ -136,6 +136,12 @@ pf_status pf_ct_pt_mul_fanout(pf_ctx *ctx, const uint64_t *ct, const uint64_t *p
 pf_status pf_pack_rows(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly,
                        uint64_t *out, pf_stream stream);
 
+/* pf_pack_rows followed by pf_ntt_forward in ONE kernel: the block is packed from the base rows straight into the
+ * registers of the forward transform, so the coefficient-form plaintext never exists in memory (1 write per
+ * coefficient instead of 2 writes + 1 read).  out [n_polys][L][N] in NTT form, bit for bit what the two calls give. */
+pf_status pf_pack_rows_ntt(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly,
+                           uint64_t *out, pf_stream stream);
+
 /* ---- plaintext distance stages ---------------------------------------------------------------- */
 /* faiss::IndexFlatL2(d) + add(nb, xb): copies the base matrix [nb][d] fp32 (host or device pointer)
  * into HBM and precomputes row norms.  Blocking. */

@@ -152,9 +152,10 @@ class RnsContext:
         check(lib.pf_apply_galois(self._h, pi, po, polys.numel() // self.N, int(galois_elt), _stream(self.device)), "pf_apply_galois")
         return out
 
-    def pack_rows(self, flat, ids, out=None):
+    def pack_rows(self, flat, ids, out=None, ntt=False):
         """Plaintext polynomials of the encrypted precise search: ids [n_polys, rows_per_poly] (int64, device) rows of
-        the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_)."""
+        the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_), or, with
+        ntt=True, directly their NTT form (packing fused into the forward transform)."""
         if ids.dim() != 2:
             raise ValueError("ids must be [n_polys, rows_per_poly]")
         n_polys, rows = ids.shape
@@ -163,7 +164,8 @@ class RnsContext:
         pi, po = _req(ids, torch.int64, self.device_index, "ids"), _req(out, torch.int64, self.device_index, "out")
         if out.numel() != n_polys * self.L * self.N:
             raise ValueError("out must hold n_polys * L * N residues")
-        check(lib.pf_pack_rows(self._h, flat._h, pi, n_polys, rows, po, _stream(self.device)), "pf_pack_rows")
+        fn = lib.pf_pack_rows_ntt if ntt else lib.pf_pack_rows
+        check(fn(self._h, flat._h, pi, n_polys, rows, po, _stream(self.device)), "pf_pack_rows_ntt" if ntt else "pf_pack_rows")
         return out
 
     def key_switch_(self, target, ksk, ct):

@@ -833,4 +833,19 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
     }
 }
 
+// Forward transform of a polynomial that is PRODUCED instead of read: `load(r, tid)` fills register k with coefficient
+// koff(0, k) + tid (canonical).  Used for plaintexts packed on the fly from base rows.
+template <class G, class A, class Loader, class Sync>
+PF_HD void body_ntt_fwd_from(const A &ar, const typename A::Tw *__restrict__ tw, const Loader &load, uint64_t *dst, typename A::V *lds,
+                             int tid, Sync &&sync) {
+    typename A::V r[G::R];
+    load(r, tid);
+    fwd_all<G, A>(r, ar, tw, lds, tid, sync);
+    canon_all<G, A>(r, ar);
+    uint64_t o[G::R];
+#pragma unroll
+    for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
+    store_last<G>(o, dst, tid);
+}
+
 }  // namespace pf

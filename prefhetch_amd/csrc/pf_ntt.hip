@@ -276,6 +276,19 @@ pf_status pf_ct_pt_mul_fanout(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_
     return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);
 }
 
+pf_status pf_pack_rows_ntt(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly, uint64_t *out,
+                           pf_stream stream) {
+    if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");
+    if (n_polys == 0) return PF_OK;
+    if (!ids || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    size_t nb = 0; uint32_t d = 0; int dev = 0;
+    const float *xb = flat_base_device(idx, &nb, &d, &dev);
+    if (dev != c->device) return fail(PF_ERR_INVALID_ARG, "context and index live on different devices");
+    if (rows_per_poly == 0 || (size_t)rows_per_poly * d > c->N) return fail(PF_ERR_INVALID_ARG, "rows_per_poly must be in [1, N / d]");
+    NttArgs a{c->d_limbs, c->d_tables, nullptr, out, nullptr, 0, c->L, 0u, 0u, 0u, xb, ids, nb, d, rows_per_poly};
+    return run_ntt_like(c, 4, 0, a, n_polys * (size_t)c->L, stream);
+}
+
 pf_status pf_pack_rows(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly, uint64_t *out,
                        pf_stream stream) {
     if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");

@@ -30,6 +30,8 @@ struct NttArgs {
     uint32_t pt_broadcast;
     uint32_t ks_decomp;      // key switching: number of digits (data limbs); L above is then the key-modulus count K
     uint32_t ct_fanout;      // ct x pt only: consecutive outputs that share one input ciphertext (0 or 1: none)
+    // k_rows_ntt: the polynomial is packed on the fly from rows of a base matrix
+    const float *rows_xb; const int64_t *rows_ids; size_t rows_nb; uint32_t rows_d, rows_per_poly;
 };
 
 template <class A> struct ArithOf;
@@ -107,6 +109,56 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ct
                            p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
 }
 
+// Plaintext packing fused into the forward transform (pf_pack_rows_ntt): block b of candidate rows is packed as
+// pf_pack_rows does (coefficient d*j - i <- x[ids[b][j]][i], negated on wrap-around) straight into the registers of the
+// transform -- consecutive lanes read consecutive floats of one row, backwards -- so the coefficient-form plaintext
+// never exists in memory.
+// Coefficient c holds x[row jj][i] with jj = ceil(c / d), i = jj*d - c; jj == N/d is row 0 negated (the wrap-around),
+// jj in [rows, N/d) is empty.  Register k of thread tid is coefficient k*T + tid, so when d divides T (d = 128 with
+// T = 256) i does not depend on k and jj advances by T/d per register: one division per thread.
+template <class G, class A>
+struct RowsLoader {
+    const float *xb; const int64_t *ids; size_t nb; uint32_t d, rows; uint64_t q;
+    __device__ __forceinline__ typename A::V fetch(uint32_t jj, uint32_t i) const {
+        const bool wrap = jj == G::N / d;
+        const uint32_t j = wrap ? 0u : jj;
+        float v = 0.f;
+        if (wrap || jj < rows) {
+            const int64_t id = ids[j];
+            if (id >= 0 && (size_t)id < nb) v = rintf(xb[(size_t)id * d + i]);
+        }
+        if (wrap) v = -v;
+        const int64_t iv = (int64_t)v;
+        return A::from_u64(iv >= 0 ? (uint64_t)iv : q - (uint64_t)(-iv));
+    }
+    __device__ __forceinline__ void operator()(typename A::V (&r)[G::R], int tid) const {
+        if (G::T % d == 0) {                                     // workgroup-uniform
+            const uint32_t jj0 = ((uint32_t)tid + d - 1) / d, i = jj0 * d - (uint32_t)tid, step = G::T / d;
+#pragma unroll
+            for (int k = 0; k < G::R; ++k) r[k] = fetch(jj0 + (uint32_t)(G::koff(0, k) / G::T) * step, i);
+        } else {
+#pragma unroll
+            for (int k = 0; k < G::R; ++k) {
+                const uint32_t c = (uint32_t)(G::koff(0, k) + tid), jj = (c + d - 1) / d;
+                r[k] = fetch(jj, jj * d - c);
+            }
+        }
+    }
+};
+
+template <int LOGN, class A>
+__global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_rows_ntt(NttArgs p) {
+    using G = Geo<LOGN>;
+    __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    const size_t poly = blockIdx.x;                              // plaintext block * L + limb
+    const uint32_t limb = (uint32_t)(poly % p.L);
+    const size_t block = poly / p.L;
+    const LimbDev &lm = p.limbs[limb];
+    const A ar = ArithOf<A>::make(lm);
+    const RowsLoader<G, A> load{p.rows_xb, p.rows_ids + block * p.rows_per_poly, p.rows_nb, p.rows_d, p.rows_per_poly, lm.q};
+    body_ntt_fwd_from<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), load, p.dst + poly * G::N, lds, (int)threadIdx.x, WgSync{});
+}
+
 // Element-wise kernels: 24 B (dyadic/add/sub) or 16 B (negate) of HBM traffic per coefficient, HBM-bound.
 // A block covers CHUNK consecutive coefficients of one limb-polynomial, 16 B per lane per access.
 enum EwOp : int { EW_MUL = 0, EW_ADD = 1, EW_SUB = 2, EW_NEG = 3 };
@@ -155,7 +207,7 @@ __global__ void __launch_bounds__(256) k_elementwise(EwArgs p) {
 
 namespace pf {
 // Defined in pf_ntt_inst.hip, one per ring degree.  arith: 0 = ArithF64, 1 = ArithU64, 2 = ArithU64L;
-// op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`, 3 key-switch digit NTT.
+// op: 0 forward NTT, 1 inverse NTT, 2 fused ct x pt with `flags`, 3 key-switch digit NTT, 4 forward NTT of plaintexts packed on the fly from base rows.
 #define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
 PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14) PF_DECL_LAUNCH(15)
 #undef PF_DECL_LAUNCH

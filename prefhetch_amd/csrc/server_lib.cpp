@@ -351,8 +351,8 @@ void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::
     im.d_pt.reserve(im.device, polys * ENC_LIMBS * ENC_RING_DEGREE * 8);
     uint64_t *pt = static_cast<uint64_t *>(im.d_pt.ptr);
     check(pf_memcpy_h2d(im.device, im.d_ids.ptr, padded.data(), padded.size() * 8, nullptr), "h2d");
-    check(pf_pack_rows(im.ring, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, pt, nullptr), "pf_pack_rows");
-    check(pf_ntt_forward(im.ring, pt, polys * ENC_LIMBS, nullptr), "pf_ntt_forward");
+    // plaintexts: packed from the candidate rows inside the forward transform
+    check(pf_pack_rows_ntt(im.ring, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, pt, nullptr), "pf_pack_rows_ntt");
     // the query ciphertexts are transformed once (on a copy), not once per plaintext block
     constexpr size_t ct_words = static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS * ENC_RING_DEGREE;
     im.d_query.reserve(im.device, ct_words * 8);

@@ -202,3 +202,27 @@ def test_pack_rows_matches_the_definition(N, qs, rows):
     assert got.shape == exp.shape and (got == exp).all()
     with pytest.raises(pf.PfError):
         ctx.pack_rows(flat, torch.zeros((1, N // d + 1), dtype=torch.int64, device=dev))
+
+
+@pytest.mark.parametrize("N,qs,rows,force", [(8192, oracle.BFV_DEFAULT[8192][:4], 64, 0), (1024, oracle.BFV_DEFAULT[1024], 8, 0),
+                                             (4096, oracle.BFV_DEFAULT[4096][:2], 17, 1), (8192, oracle.BFV_DEFAULT[8192][:4], 64, 2)])
+def test_pack_rows_ntt_equals_pack_then_transform(N, qs, rows, force):
+    """pf_pack_rows_ntt (packing fused into the forward transform) against pack_rows -> ntt_forward and against the
+    oracle, bit for bit, on every arithmetic back-end."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(N * 3 + rows)
+    nb, d, n_polys = 2000, 128, 7
+    base = rng.integers(0, 256, (nb, d)).astype(np.float32)
+    base[5] = -base[5]
+    ids = rng.integers(0, nb, (n_polys, rows)).astype(np.int64)
+    ids[0, 0], ids[1, rows - 1], ids[2, 0] = 5, -1, nb + 3
+    flat = pf.FlatL2(base, dev)
+    ctx = pf.RnsContext(N, qs, dev)
+    if force:
+        ctx.force_u64(force)
+    d_ids = torch.from_numpy(ids).to(dev)
+    fused = pf.to_host_u64(ctx.pack_rows(flat, d_ids, ntt=True))
+    two = pf.to_host_u64(ctx.ntt_forward_(ctx.pack_rows(flat, d_ids)))
+    assert (fused == two).all()
+    assert (fused == oracle.Oracle(N, qs).ntt_forward(oracle.pack_rows(base, ids, N, qs))).all()
