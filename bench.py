@@ -140,7 +140,7 @@ def main():
     gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    side = torch.cuda.Stream(device=dev) if args.overlap else None
+    side = torch.cuda.Stream(device=dev, priority=-1) if args.overlap else None     # high priority: its workgroups take the CU slots the matrix stage frees
 
     def step(i=None):
         e = ev[i] if i is not None else None
