@@ -45,7 +45,7 @@ for name, N, L, B in SHAPES:
     res = torch.empty_like(ct)
     ctx = pf.RnsContext(N, qs, dev)
     reps = 20 if N < 32768 else 5
-    rec = {"shape": name, "N": N, "limbs": L, "batch": B, "arith_path": "exact-FP64" if ctx.info()["arith_path"][0] == 0 else "u64 Shoup/Harvey"}
+    rec = {"shape": name, "N": N, "limbs": L, "batch": B, "arith_path": {0: "exact-FP64", 1: "u64 Harvey/Shoup", 2: "u64 lazy (q < 2^56)"}[ctx.info()["arith_path"][0]]}
     for kname, fn, bytes_per in (
         ("ct_x_pt_fused", lambda: ctx.ct_pt_mul(ct, pt, out=res), 40 * L * N * B),
         ("ntt_forward", lambda: ctx.ntt_forward_(res), 16 * N * 2 * L * B),
