@@ -240,8 +240,7 @@ def main():
 
         def fused_kernel():                                                 # what Server::preciseSearchEncrypted runs
             ctx.pack_rows(flat, ids, out=ptb, ntt=True)                     # packing inside the forward transform
-            ctn.copy_(ct)
-            ctx.ntt_forward_(ctn)
+            ctx.ntt_forward(ct, out=ctn)                                    # out of place: the caller's ciphertexts stay as they are
             ctx.ct_pt_mul_fanout(ctn, ptb, fan, out=res, flags=2)
 
         def timed(fn, reps=5):

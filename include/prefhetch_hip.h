@@ -80,6 +80,10 @@ pf_status pf_ctx_force_u64(pf_ctx *ctx, int on);
 pf_status pf_ntt_forward(pf_ctx *ctx, uint64_t *polys, size_t n_limb_polys, pf_stream stream);
 /* util::inverse_ntt_negacyclic_harvey: in-place inverse, bit-reversed in, natural out, scaled by N^-1. */
 pf_status pf_ntt_inverse(pf_ctx *ctx, uint64_t *polys, size_t n_limb_polys, pf_stream stream);
+/* The same transforms from `src` into `dst` (Evaluator::transform_to_ntt / transform_from_ntt with a destination):
+ * src is left untouched; dst may equal src. */
+pf_status pf_ntt_forward_to(pf_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t n_limb_polys, pf_stream stream);
+pf_status pf_ntt_inverse_to(pf_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t n_limb_polys, pf_stream stream);
 /* util::dyadic_product_coeffmod: out[i] = a[i]*b[i] mod q.  out may alias a or b. */
 pf_status pf_dyadic_mul(pf_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_limb_polys, pf_stream stream);
 /* util::add_poly_coeffmod / sub_poly_coeffmod / negate_poly_coeffmod (Evaluator::add_inplace etc.). */

@@ -14,7 +14,7 @@ SYMBOLS = [
     "pf_status_str", "pf_last_error", "pf_device_count",
     "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_memcpy_d2d", "pf_stream_synchronize",
     "pf_ctx_create", "pf_ctx_destroy", "pf_ctx_info", "pf_ctx_force_u64",
-    "pf_ntt_forward", "pf_ntt_inverse", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
+    "pf_ntt_forward", "pf_ntt_inverse", "pf_ntt_forward_to", "pf_ntt_inverse_to", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
     "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_key_switch", "pf_pack_rows", "pf_pack_rows_ntt",
     "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
     "pf_flat_reserve",
@@ -52,6 +52,8 @@ def _load():
     lib.pf_ctx_force_u64.argtypes = [vp, i32]
     lib.pf_ntt_forward.argtypes = [vp, vp, sz, vp]
     lib.pf_ntt_inverse.argtypes = [vp, vp, sz, vp]
+    lib.pf_ntt_forward_to.argtypes = [vp, vp, vp, sz, vp]
+    lib.pf_ntt_inverse_to.argtypes = [vp, vp, vp, sz, vp]
     for name in ("pf_dyadic_mul", "pf_poly_add", "pf_poly_sub"):
         getattr(lib, name).argtypes = [vp, vp, vp, vp, sz, vp]
     lib.pf_poly_negate.argtypes = [vp, vp, vp, sz, vp]

@@ -81,6 +81,19 @@ class RnsContext:
         check(lib.pf_ntt_forward(self._h, p, self._count(polys), _stream(self.device)), "pf_ntt_forward")
         return polys
 
+    def ntt_forward(self, polys, out=None):
+        """out-of-place forward transform (polys untouched)"""
+        out = torch.empty_like(polys) if out is None else out
+        ps, pd = _req(polys, torch.int64, self.device_index, "polys"), _req(out, torch.int64, self.device_index, "out")
+        check(lib.pf_ntt_forward_to(self._h, ps, pd, self._count(polys), _stream(self.device)), "pf_ntt_forward_to")
+        return out
+
+    def ntt_inverse(self, polys, out=None):
+        out = torch.empty_like(polys) if out is None else out
+        ps, pd = _req(polys, torch.int64, self.device_index, "polys"), _req(out, torch.int64, self.device_index, "out")
+        check(lib.pf_ntt_inverse_to(self._h, ps, pd, self._count(polys), _stream(self.device)), "pf_ntt_inverse_to")
+        return out
+
     def ntt_inverse_(self, polys):
         p = _req(polys, torch.int64, self.device_index, "polys")
         check(lib.pf_ntt_inverse(self._h, p, self._count(polys), _stream(self.device)), "pf_ntt_inverse")

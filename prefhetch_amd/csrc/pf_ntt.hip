@@ -235,17 +235,20 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
     return PF_OK;
 }
 
-pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
-    if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0, 0};
+pf_status pf_ntt_forward_to(pf_ctx *c, const uint64_t *src, uint64_t *dst, size_t n, pf_stream stream) {
+    if (!c || ((!src || !dst) && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    NttArgs a{c->d_limbs, c->d_tables, src, dst, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
-pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) {
-    if (!c || (!polys && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    NttArgs a{c->d_limbs, c->d_tables, polys, polys, nullptr, 0, c->L, 0, 0};
+pf_status pf_ntt_inverse_to(pf_ctx *c, const uint64_t *src, uint64_t *dst, size_t n, pf_stream stream) {
+    if (!c || ((!src || !dst) && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    NttArgs a{c->d_limbs, c->d_tables, src, dst, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
+
+pf_status pf_ntt_forward(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) { return pf_ntt_forward_to(c, polys, polys, n, stream); }
+pf_status pf_ntt_inverse(pf_ctx *c, uint64_t *polys, size_t n, pf_stream stream) { return pf_ntt_inverse_to(c, polys, polys, n, stream); }
 
 pf_status pf_dyadic_mul(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_MUL, a, b, out, n, s); }
 pf_status pf_poly_add(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n, pf_stream s) { return run_elementwise(c, EW_ADD, a, b, out, n, s); }

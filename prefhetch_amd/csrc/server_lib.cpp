@@ -353,12 +353,11 @@ void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::
     check(pf_memcpy_h2d(im.device, im.d_ids.ptr, padded.data(), padded.size() * 8, nullptr), "h2d");
     // plaintexts: packed from the candidate rows inside the forward transform
     check(pf_pack_rows_ntt(im.ring, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, pt, nullptr), "pf_pack_rows_ntt");
-    // the query ciphertexts are transformed once (on a copy), not once per plaintext block
+    // the query ciphertexts are transformed once (into a scratch buffer), not once per plaintext block
     constexpr size_t ct_words = static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS * ENC_RING_DEGREE;
     im.d_query.reserve(im.device, ct_words * 8);
     uint64_t *qn = static_cast<uint64_t *>(im.d_query.ptr);
-    check(pf_memcpy_d2d(im.device, qn, query_ct_device, ct_words * 8, nullptr), "d2d");
-    check(pf_ntt_forward(im.ring, qn, static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS, nullptr), "pf_ntt_forward");
+    check(pf_ntt_forward_to(im.ring, query_ct_device, qn, static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS, nullptr), "pf_ntt_forward_to");
     check(pf_ct_pt_mul_fanout(im.ring, qn, pt, result_ct_device, polys, ENC_POLYS_PER_QUERY, PF_CTPT_IN_NTT, nullptr), "pf_ct_pt_mul_fanout");
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }

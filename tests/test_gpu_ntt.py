@@ -309,3 +309,16 @@ def test_apply_galois(pf, N, qs):
         c.apply_galois(d, 4)
     with pytest.raises(pf.PfError):
         c.apply_galois(d, 3, out=d)
+
+
+def test_out_of_place_transforms(pf):
+    N, qs = 4096, oracle.BFV_DEFAULT[4096][:2]
+    rng = np.random.default_rng(9)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(3)])
+    d = pf.to_device_u64(a, _dev())
+    f = c.ntt_forward(d)
+    assert (pf.to_host_u64(d) == a).all()                              # source untouched
+    assert (pf.to_host_u64(f) == o.ntt_forward(a)).all()
+    assert (pf.to_host_u64(c.ntt_inverse(f)) == a).all()
