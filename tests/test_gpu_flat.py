@@ -29,7 +29,8 @@ def _sift_like(rng, n, d=128):
 
 
 @pytest.mark.parametrize("nb,nq,k", [(10000, 5, 100), (10000, 5, 200), (10000, 130, 20), (256, 5, 256), (1000, 1, 1),
-                                      (33000, 257, 200), (100, 3, 200), (4097, 7, 1024)])
+                                      (33000, 257, 200), (100, 3, 200), (4097, 7, 1024),
+                                      (300000, 3, 200), (70000, 48, 100), (70000, 64, 50), (150000, 33, 10)])   # 32- / 64-row query tiles, streaming chunks
 def test_flat_search_integer_data_exact(pf, nb, nq, k):
     rng = np.random.default_rng(nb + nq + k)
     xb, xq = _sift_like(rng, nb), _sift_like(rng, nq)
