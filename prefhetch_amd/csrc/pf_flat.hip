@@ -137,7 +137,8 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
     }
 }
 
-template <bool FILTER, class GEO, bool FAST>
+// AGG: survivors are aggregated per row in LDS before the global append (few queries: the global counters are hot).
+template <bool FILTER, class GEO, bool FAST, bool AGG = (GEO::TM <= 64)>
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
     __shared__ float sAb[2][TK * LDA];            // two k-slabs in flight: one feeds the MFMAs, the next is being filled
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             const bool ok = q0 + tid < p.nq;
             sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
             sA[TM + tid] = ok ? p.tau[q0 + tid] : -INFINITY;        // rows past nq: nothing passes
+            reinterpret_cast<uint32_t *>(sA)[2 * TM + tid] = 0;     // per-row survivor count of this workgroup (small batches)
         }
         __syncthreads();
     }
@@ -226,6 +228,58 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         col[jj] = c0 + wn + 32 * jj + (lane & 31);
         col_ok[jj] = col[jj] < p.nb_count;
         bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : 0.f;
+    }
+    if constexpr (FILTER && AGG) {
+        // Small batches: few queries take every survivor of the chunk, so one global atomic per half-wave would
+        // serialise on a handful of counters.  Survivors are first counted per row in LDS, then each row reserves its
+        // range with ONE global atomic per workgroup, then the keys are written.
+        uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sA) + 2 * TM, *s_base = s_cnt + TM;
+        auto verdict = [&](int i, int r, float (&dist)[NJ], bool (&pass)[NJ], uint32_t (&hm)[NJ]) {
+            const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float qnv = sA[lrow], tv = sA[TM + lrow];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
+                pass[jj] = col_ok[jj] && dist[jj] <= tv;
+                hm[jj] = (uint32_t)(__ballot(pass[jj]) >> (lane & 32));
+                tot += __popc(hm[jj]);
+            }
+            return tot;
+        };
+        uint32_t loc[MI][16];                                        // offset of this half-wave inside its row's range
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
+                const uint32_t tot = verdict(i, r, dist, pass, hm);
+                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                loc[i][r] = ((lane & 31) == 0 && tot) ? atomicAdd(&s_cnt[lrow], tot) : 0u;
+            }
+        __syncthreads();
+        if (tid < TM) { const uint32_t n = s_cnt[tid]; s_base[tid] = n ? atomicAdd(&p.cand_cnt[q0 + tid], n) : 0u; }
+        __syncthreads();
+        const uint32_t below = (1u << (lane & 31)) - 1u;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
+                if (__ballot(verdict(i, r, dist, pass, hm) != 0) == 0) continue;
+                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const size_t row = q0 + lrow;
+                uint32_t base = s_base[lrow] + __shfl(loc[i][r], lane & 32);
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    if (pass[jj]) {
+                        const uint32_t pos = base + __popc(hm[jj] & below);
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj] < 0.f ? 0.f : dist[jj], (uint32_t)(p.nb_first + col[jj]));
+                    }
+                    base += __popc(hm[jj]);
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -616,7 +670,12 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
             case 2: PF_TILE(false, GeoSmall64); break;
             case 3: PF_TILE(true, GeoSmall64); break;
             case 4: PF_TILE(false, GeoBatch); break;
-            default: PF_TILE(true, GeoBatch); break;
+            default:
+                if (nq <= 512) {                       // up to four query tiles: aggregate per workgroup (32 more VGPRs, 3 waves/SIMD)
+                    if (fast) hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, true, true>), grid, dim3(256), 0, s, t);
+                    else hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, false, true>), grid, dim3(256), 0, s, t);
+                } else PF_TILE(true, GeoBatch);
+                break;
         }
 #undef PF_TILE
     };
