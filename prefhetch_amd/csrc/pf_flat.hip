@@ -41,7 +41,9 @@ constexpr int KQ = TK / 4;                        // lanes covering one row of a
 #endif
 constexpr uint32_t SEL_CAP = PF_SEL_CAP;          // reservoir capacity (keys)
 constexpr uint32_t K_MAX = 1024;                  // largest k
-constexpr uint32_t SEL_THREADS = 256;
+// k_select: one workgroup per query, of 1024 threads when there are few queries (at most one workgroup per CU: the in-LDS
+// sorts run with every pair on its own thread) and of 256 threads for batches (more workgroups resident per CU)
+constexpr uint32_t SEL_ROUND = 1024;              // keys a reservoir round can add
 constexpr uint64_t KEY_INF = 0x7F800000FFFFFFFFull;   // (+inf, id 2^32-1): sorts after every real key
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -346,6 +348,7 @@ struct SelArgs {
 };
 
 // in-LDS bitonic sort of the first n keys (n a power of two <= SEL_CAP; the rest must already be KEY_INF), ascending
+template <uint32_t THREADS>
 __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n = SEL_CAP) {
     // Pair t of a step touches elements 2t - (t & (stride-1)) and + stride.  A wave always owns the same 64 consecutive
     // pairs, which for stride <= 64 live in one aligned block of 128 elements: such steps only exchange data inside
@@ -355,7 +358,7 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             if (stride > 64 || (stride == 64 && size > 128)) __syncthreads();
             else __builtin_amdgcn_wave_barrier();
-            for (uint32_t t = tid; t < n / 2; t += SEL_THREADS) {
+            for (uint32_t t = tid; t < n / 2; t += THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -367,27 +370,30 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n
     __syncthreads();
 }
 
-// Reservoir scan of columns [0, nb_count): `dist4(col, v)` yields the distances of columns col..col+3.
-// Rounds of 4 columns per thread add at most 1024 keys, so the reservoir is compacted when fewer slots remain.
-template <class Dist4>
+// Reservoir scan of columns [0, nb_count): `dists(col, v)` yields the distances of columns col .. col+SEL_COLS-1.
+// A round adds at most 1024 keys, so the reservoir is compacted when fewer slots remain.
+template <uint32_t THREADS, class Dists>
 __device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, uint64_t &tau, uint32_t k, size_t nb_first,
-                                               size_t nb_count, int tid, Dist4 &&dist4) {
-    for (size_t base = 0; base < nb_count; base += SEL_THREADS * 4) {
+                                               size_t nb_count, int tid, Dists &&dists) {
+    constexpr int SEL_COLS = SEL_ROUND / THREADS;
+    for (size_t base = 0; base < nb_count; base += SEL_ROUND) {
         const uint32_t c = cnt;                               // stable here: a barrier separates it from every add
         __syncthreads();                                      // ... and everyone has read it before the next add
-        if (c > SEL_CAP - SEL_THREADS * 4) {                  // workgroup-uniform
-            bitonic_sort(keys, tid);
+        if (c > SEL_CAP - SEL_ROUND) {                        // workgroup-uniform
+            bitonic_sort<THREADS>(keys, tid);
             if (tid == 0) { cnt = c < k ? c : k; tau = c >= k ? keys[k - 1] : KEY_INF; }
             __syncthreads();
-            for (uint32_t i = cnt + tid; i < SEL_CAP; i += SEL_THREADS) keys[i] = KEY_INF;
+            for (uint32_t i = cnt + tid; i < SEL_CAP; i += THREADS) keys[i] = KEY_INF;
             __syncthreads();
         }
         const uint64_t t = tau;
-        const size_t col = base + (size_t)tid * 4;
-        float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-        if (col < nb_count) dist4(col, v);
+        const size_t col = base + (size_t)tid * SEL_COLS;
+        float v[SEL_COLS];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < SEL_COLS; ++e) v[e] = INFINITY;
+        if (col < nb_count) dists(col, v);
+#pragma unroll
+        for (int e = 0; e < SEL_COLS; ++e) {
             if (col + e < nb_count) {
                 const uint64_t key = make_key(v[e], (uint32_t)(nb_first + col + e));
                 if (key < t) { const uint32_t pos = atomicAdd(&cnt, 1u); keys[pos] = key; }
@@ -399,7 +405,9 @@ __device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, ui
 
 // One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
 // running top-k, or -- if the candidate list overflowed -- rescan the chunk exactly.
-__global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
+template <uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
+    constexpr int SEL_COLS = SEL_ROUND / THREADS;
     __shared__ uint64_t keys[SEL_CAP];
     __shared__ uint32_t cnt;
     __shared__ uint64_t tau;
@@ -409,7 +417,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
     const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
     const uint32_t nc = p.mode == 1 ? p.cand_cnt[q] : 0u;
     const bool merge = p.mode == 1 && nc <= p.cap;            // workgroup-uniform
-    for (uint32_t i = tid; i < SEL_CAP; i += SEL_THREADS) {
+    for (uint32_t i = tid; i < SEL_CAP; i += THREADS) {
         uint64_t v = KEY_INF;
         if (i < c0) v = p.state[q * k + i];
         else if (merge && i - c0 < nc) v = p.cand[q * p.cap + (i - c0)];     // c0 + nc <= k + cap <= SEL_CAP
@@ -420,20 +428,22 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
     if (p.mode == 0) {
         const float *row = p.slab + q * (size_t)p.slab_ld;
         const bool vec = (p.slab_ld & 3) == 0;
-        reservoir_scan(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[4]) {
-            if (vec && col + 3 < p.nb_count) {
-                const float4 f = *reinterpret_cast<const float4 *>(row + col);
-                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-            } else {
-                for (int e = 0; e < 4; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
+        reservoir_scan<THREADS>(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[SEL_COLS]) {
+            if constexpr (SEL_COLS == 4) {
+                if (vec && col + 3 < p.nb_count) {
+                    const float4 f = *reinterpret_cast<const float4 *>(row + col);
+                    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                    return;
+                }
             }
+            for (int e = 0; e < SEL_COLS; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
         });
     } else if (!merge) {
         // overflow: the same k-ordered fmaf chain the matrix pipe evaluates, one base row at a time
         const float *x = p.xq + q * (size_t)p.d;
         const float qn = p.qn[q];
-        reservoir_scan(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[4]) {
-            for (int e = 0; e < 4; ++e) {
+        reservoir_scan<THREADS>(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[SEL_COLS]) {
+            for (int e = 0; e < SEL_COLS; ++e) {
                 if (col + e >= p.nb_count) break;
                 const float *y = p.xb + (p.nb_first + col + e) * (size_t)p.d;
                 float acc = 0.f;
@@ -446,17 +456,17 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select(SelArgs p) {
     // sort, keep k, carry or emit (a merge usually holds far fewer than SEL_CAP keys: sort only what is there)
     uint32_t n_sort = 64;
     while (n_sort < cnt) n_sort <<= 1;                          // cnt is stable: the scan ends with a barrier
-    bitonic_sort(keys, tid, n_sort);
+    bitonic_sort<THREADS>(keys, tid, n_sort);
     const uint32_t total = cnt < k ? cnt : k;
     if (p.last) {
-        for (uint32_t i = tid; i < k; i += SEL_THREADS) {
+        for (uint32_t i = tid; i < k; i += THREADS) {
             const uint64_t key = keys[i];
             const bool ok = i < total;
             p.D[q * k + i] = ok ? __uint_as_float((uint32_t)(key >> 32)) : INFINITY;
             p.I[q * k + i] = ok ? (int64_t)(uint32_t)key : -1;
         }
     } else {
-        for (uint32_t i = tid; i < total; i += SEL_THREADS) p.state[q * k + i] = keys[i];
+        for (uint32_t i = tid; i < total; i += THREADS) p.state[q * k + i] = keys[i];
         if (tid == 0) {
             p.state_cnt[q] = total;
             p.tau[q] = total == k ? __uint_as_float((uint32_t)(keys[k - 1] >> 32)) : INFINITY;
@@ -679,12 +689,16 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         }
 #undef PF_TILE
     };
+    auto launch_select = [&]() {
+        if (nq <= 256) hipLaunchKernelGGL(k_select<1024>, dim3((unsigned)nq), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL(k_select<256>, dim3((unsigned)nq), dim3(256), 0, s, a);
+    };
     // bootstrap chunk through the slab
     const size_t boot = f->nb < w.boot ? f->nb : w.boot;
     t.nb_first = 0; t.nb_count = boot;
     if (boot) launch_tile(false, boot);
     a.nb_first = 0; a.nb_count = boot; a.mode = 0; a.first = 1; a.last = boot == f->nb;
-    hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+    launch_select();
     // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a quarter of
     // the candidate capacity
     size_t pos = boot;
@@ -700,7 +714,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         t.nb_first = pos; t.nb_count = chunk;
         launch_tile(true, chunk);
         a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
-        hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(SEL_THREADS), 0, s, a);
+        launch_select();
         pos += chunk;
     }
     PF_HIP(hipGetLastError());
