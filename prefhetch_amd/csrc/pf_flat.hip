@@ -706,7 +706,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         size_t chunk = pos * w.cap / (4 * (size_t)k);
         chunk = chunk / 256 * 256;
         if (chunk < 4096) chunk = 4096;
-        if (chunk > MAX_CHUNK) chunk = MAX_CHUNK;
+        if (chunk > MAX_CHUNK && geo == 2) chunk = MAX_CHUNK;       // few queries: fewer, longer launches (each one has a ramp and a merge)
         // whole rounds of resident workgroups: a chunk that fills the device 1.2 times takes as long as one that fills it twice
         const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
         if (chunk > round_cols) chunk = chunk / round_cols * round_cols;
