@@ -27,42 +27,44 @@ struct DistanceIndexData {
     faiss_idx_t idx;
 };
 
+// Shapes of the protocol (aliases only: the types are the reference's std::array / std::vector types, so its callers
+// compile unchanged)
+using QueryBatch = std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY>;         // NQUERY x 128 query vectors
+using CentroidTable = std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>>;             // NLIST x 128
+using RankedLists = std::array<std::vector<DistanceIndexData>, NQUERY>;                      // per query, ascending by distance
+using PreciseScores = std::array<std::array<float, COARSE_PROBE>, NQUERY>;
+using PreciseRanking = std::array<std::array<DistanceIndexData, COARSE_PROBE>, NQUERY>;
+using ResultIds = std::array<std::array<faiss_idx_t, K>, NQUERY>;
+using ResultVectors = std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY>;
+using ListSizes = std::array<size_t, NQUERY>;
+
 // The connection the functions below use; not owned.  Without one every request throws std::runtime_error.
 void set_transport(wire::Transport *transport);
 // Device the centroid shortlist runs on (default 0).
 void set_client_device(int device);
 
-void ping_server();                                            // GET /query; throws when the server does not answer
-
+// GET /query; throws when the server does not answer
+void ping_server();
 // Reads ../sift/siftsmall/siftsmall_query.fvecs (aborts when the file is missing, like the reference).
-void get_query(std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &query);
+void get_query(QueryBatch &query);
 
-void get_centroids(std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> &centroids);
-void sort_nearest_centroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
-                            const std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> &centroids,
-                            std::array<std::vector<DistanceIndexData>, NQUERY> &nearest_centroids);
+// round 1: centroids from the server, shortlist of inverted lists on the client (reference :22-26)
+void get_centroids(CentroidTable &centroids);
+void sort_nearest_centroids(const QueryBatch &precise_query, const CentroidTable &centroids, RankedLists &nearest_centroids);
 
-void get_coarse_scores(const std::array<std::vector<DistanceIndexData>, NQUERY> &sorted_centroids,
-                       const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
-                       std::vector<float> &coarse_scores, std::vector<faiss_idx_t> &coarse_vectors_idx,
-                       std::array<size_t, NQUERY> &list_sizes_per_query_coarse);
+// round 2: PQ scores of every vector of the NPROBE nearest lists, ranked on the client (reference :32-48)
+void get_coarse_scores(const RankedLists &sorted_centroids, const QueryBatch &precise_query, std::vector<float> &coarse_scores,
+                       std::vector<faiss_idx_t> &coarse_vectors_idx, ListSizes &list_sizes_per_query_coarse);
+void compute_nearest_coarse_vectors(const std::vector<float> &coarse_distance_scores, const std::vector<faiss_idx_t> &coarse_vector_indexes,
+                                    const ListSizes &list_sizes_per_query_coarse, RankedLists &nearest_coarse_vectors_idx);
 
-void compute_nearest_coarse_vectors(const std::vector<float> &coarse_distance_scores,
-                                    const std::vector<faiss_idx_t> &coarse_vector_indexes,
-                                    const std::array<size_t, NQUERY> &list_sizes_per_query_coarse,
-                                    std::array<std::vector<DistanceIndexData>, NQUERY> &nearest_coarse_vectors_idx);
+// round 3: exact distances of the COARSE_PROBE best candidates, ranked on the client (reference :50-62)
+void get_precise_scores(const RankedLists &sorted_coarse_vectors, const QueryBatch &precise_query, PreciseScores &precise_scores);
+void compute_nearest_precise_vectors(const PreciseScores &precise_scores, const RankedLists &sorted_coarse_vectors,
+                                     PreciseRanking &nearest_precise_vectors);
 
-void get_precise_scores(const std::array<std::vector<DistanceIndexData>, NQUERY> &sorted_coarse_vectors,
-                        const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
-                        std::array<std::array<float, COARSE_PROBE>, NQUERY> &precise_scores);
-
-void compute_nearest_precise_vectors(const std::array<std::array<float, COARSE_PROBE>, NQUERY> &precise_scores,
-                                     const std::array<std::vector<DistanceIndexData>, NQUERY> &sorted_coarse_vectors,
-                                     std::array<std::array<DistanceIndexData, COARSE_PROBE>, NQUERY> &nearest_precise_vectors);
-
-void get_precise_vectors_pir(const std::array<std::array<DistanceIndexData, COARSE_PROBE>, NQUERY> &nearest_precise_vectors,
-                             std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY> &query_results,
-                             std::array<std::array<faiss_idx_t, K>, NQUERY> &query_results_idx);
+// round 4: the K best vectors themselves (reference :64-69)
+void get_precise_vectors_pir(const PreciseRanking &nearest_precise_vectors, ResultVectors &query_results, ResultIds &query_results_idx);
 
 // Recall@{1,10,100} and MRR@{1,10,100} exactly as the reference counts them (client_lib.cpp:243-337): ground-truth
 // neighbour j < K of query i is a hit at the position k < K where it appears in the observed results; recall@R counts
@@ -71,7 +73,6 @@ struct RecallStats {
     float recall_1, recall_10, recall_100;
     float mrr_1, mrr_10, mrr_100;
 };
-RecallStats compute_recall_stats(const std::array<std::array<faiss_idx_t, K>, NQUERY> &observed_query_results_idx,
-                                 const std::vector<int> &ground_truth, size_t gt_nn_per_query);
+RecallStats compute_recall_stats(const ResultIds &observed_query_results_idx, const std::vector<int> &ground_truth, size_t gt_nn_per_query);
 // Reads ../sift/siftsmall/siftsmall_groundtruth.ivecs and prints the reference's report.
-void benchmark_results(const std::array<std::array<faiss_idx_t, K>, NQUERY> &query_results_idx);
+void benchmark_results(const ResultIds &query_results_idx);
