@@ -143,7 +143,7 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
 template <bool FILTER, class GEO, bool FAST, bool AGG = (GEO::TM <= 64)>
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
-    __shared__ float sAb[2][TK * LDA];            // two k-slabs in flight: one feeds the MFMAs, the next is being filled
+    __shared__ __align__(16) float sAb[2][TK * LDA];   // two k-slabs in flight: one feeds the MFMAs, the next is being filled
     __shared__ float sBb[2][TK * LDB];
     float *const sA = sAb[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,6 +166,20 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
+    // operands of the epilogue, requested now so that their latency hides under the whole tile: the norms of this lane's
+    // columns (NaN past the end of the chunk when filtering: such a distance compares false with every threshold) and,
+    // for the first TM threads, one query row's (norm, threshold)
+    size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        col[jj] = c0 + wn + 32 * jj + (lane & 31);
+        col_ok[jj] = col[jj] < p.nb_count;
+        bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : (FILTER ? __builtin_nanf("") : 0.f);
+    }
+    float row_qn = 0.f, row_tau = -INFINITY;                      // rows past nq: nothing passes
+    if constexpr (FILTER) {
+        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
+    }
     float4 ra[GEO::ITA], rb[GEO::ITB];
     slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
     slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
@@ -216,20 +230,12 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     if constexpr (FILTER) {
         // per-query norm and threshold of this tile's rows, staged in LDS (sA is free now)
         __syncthreads();
-        if (tid < TM) {
-            const bool ok = q0 + tid < p.nq;
-            sA[tid] = ok ? p.qn[q0 + tid] : 0.f;
-            sA[TM + tid] = ok ? p.tau[q0 + tid] : -INFINITY;        // rows past nq: nothing passes
+        if (tid < TM) {                                              // (norm, threshold) pairs: one 8-byte LDS read per use
+            sA[2 * tid] = row_qn;
+            sA[2 * tid + 1] = row_tau;
             reinterpret_cast<uint32_t *>(sA)[2 * TM + tid] = 0;     // per-row survivor count of this workgroup (small batches)
         }
         __syncthreads();
-    }
-    size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        col[jj] = c0 + wn + 32 * jj + (lane & 31);
-        col_ok[jj] = col[jj] < p.nb_count;
-        bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : 0.f;
     }
     if constexpr (FILTER && AGG) {
         // Small batches: few queries take every survivor of the chunk, so one global atomic per half-wave would
@@ -238,12 +244,13 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sA) + 2 * TM, *s_base = s_cnt + TM;
         auto verdict = [&](int i, int r, float (&dist)[NJ], bool (&pass)[NJ], uint32_t (&hm)[NJ]) {
             const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float qnv = sA[lrow], tv = sA[TM + lrow];
+            const float2 qt = *reinterpret_cast<const float2 *>(sA + 2 * lrow);
+            const float qnv = qt.x, tv = qt.y;
             uint32_t tot = 0;
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                pass[jj] = col_ok[jj] && dist[jj] <= tv;
+                pass[jj] = dist[jj] <= tv;
                 hm[jj] = (uint32_t)(__ballot(pass[jj]) >> (lane & 32));
                 tot += __popc(hm[jj]);
             }
@@ -285,6 +292,14 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        // the (norm, threshold) pairs of eight accumulator registers are fetched from LDS together: one latency per
+        // batch instead of one per register (the reads cannot be hoisted over the branches below by the compiler)
+        float2 qts[16];
+        if constexpr (FILTER) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                qts[r] = *reinterpret_cast<const float2 *>(sA + 2 * (wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)));
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -292,18 +307,20 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             if constexpr (FILTER) {
                 // A half-wave holds 32 columns of ONE query per register: survivors (ties pass; k_select orders by
                 // (distance, id)) are counted with a ballot and appended with one atomic per half-wave.
-                const float qnv = sA[lrow], tv = sA[TM + lrow];
-                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
-                bool any = false;
+                const float qnv = qts[r].x, tv = qts[r].y;
+                float dist[NJ]; bool pass[NJ]; uint64_t mask[NJ];
+                uint64_t any = 0;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
                     dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                    pass[jj] = col_ok[jj] && dist[jj] <= tv;        // tau >= 0: same verdict before and after the clamp at 0
-                    const uint64_t m = __ballot(pass[jj]);
-                    any |= m != 0;
-                    hm[jj] = (uint32_t)(m >> (lane & 32));
+                    pass[jj] = dist[jj] <= tv;                       // tau >= 0: same verdict before and after the clamp at 0
+                    mask[jj] = __ballot(pass[jj]);
+                    any |= mask[jj];
                 }
-                if (!any) continue;                                  // wave-uniform: the common case in large batches
+                if (any == 0) continue;                              // wave-uniform: the common case in large batches
+                uint32_t hm[NJ];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) hm[jj] = (uint32_t)(mask[jj] >> (lane & 32));
                 uint32_t tot = 0;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) tot += __popc(hm[jj]);
