@@ -290,61 +290,89 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             }
         return;
     }
+    if constexpr (FILTER) {
+        // Batches: the survivors of one accumulator register of one half-wave all belong to ONE query, and every query of
+        // the wave's 32*MI rows shows up in exactly one (register, half) -- so lane L can own local row L.  First sweep:
+        // count each row's survivors (ballots; the counts land in their lanes with v_writelane).  Then every lane with a
+        // non-zero count reserves its row's range with one atomic -- all rows of the wave in ONE memory round trip instead
+        // of one dependent round trip per row.  Second sweep, only over registers that had survivors: write the keys.
+        uint32_t row_cnt = 0, hit[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            hit[i] = 0;
+#pragma unroll
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+            // (norm, threshold) pairs of eight registers fetched from LDS together: one latency per batch
+            float2 qts[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                qts[e] = *reinterpret_cast<const float2 *>(sA + 2 * (wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r8 + e;
+                uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const float dist = fmaf(-2.f, acc[i][jj][r], qts[e].x + bnv[jj]);
+                    const uint64_t m = __ballot(dist <= qts[e].y);       // tau >= 0: same verdict before and after the clamp at 0
+                    t0 += __builtin_popcount((uint32_t)m);
+                    t1 += __builtin_popcount((uint32_t)(m >> 32));
+                }
+                const int rho = 32 * i + (r & 3) + 8 * (r >> 2);         // local row of half 0; half 1 is 4 rows further
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(row_cnt) : "s"(t0), "n"(rho));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(row_cnt) : "s"(t1), "n"(rho + 4));
+                hit[i] |= (uint32_t)((t0 | t1) != 0) << r;
+            }
+            }
+        }
+        uint32_t any_hit = 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) any_hit |= hit[i];
+        if (any_hit == 0) return;                                    // wave-uniform
+        uint32_t row_base = 0;
+        if (row_cnt) row_base = atomicAdd(&p.cand_cnt[q0 + wm + lane], row_cnt);      // lanes >= 32*MI hold 0
+        const uint32_t below = (1u << (lane & 31)) - 1u;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (hit[i] == 0) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!((hit[i] >> r) & 1u)) continue;                     // wave-uniform
+                const int rho = 32 * i + (r & 3) + 8 * (r >> 2);
+                const int lrow = wm + rho + 4 * (lane >> 5);
+                const size_t row = q0 + lrow;
+                const float2 qt = *reinterpret_cast<const float2 *>(sA + 2 * lrow);
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)row_base, rho);
+                const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)row_base, rho + 4);
+                uint32_t base = (lane & 32) ? b1 : b0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const float dist = fmaf(-2.f, acc[i][jj][r], qt.x + bnv[jj]);
+                    const bool pass = dist <= qt.y;
+                    const uint32_t hm = (uint32_t)(__ballot(pass) >> (lane & 32));
+                    if (pass) {
+                        const uint32_t pos = base + __popc(hm & below);
+                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, (uint32_t)(p.nb_first + col[jj]));
+                    }
+                    base += __popc(hm);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        // the (norm, threshold) pairs of eight accumulator registers are fetched from LDS together: one latency per
-        // batch instead of one per register (the reads cannot be hoisted over the branches below by the compiler)
-        float2 qts[16];
-        if constexpr (FILTER) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                qts[r] = *reinterpret_cast<const float2 *>(sA + 2 * (wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)));
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const size_t row = q0 + lrow;
-            if constexpr (FILTER) {
-                // A half-wave holds 32 columns of ONE query per register: survivors (ties pass; k_select orders by
-                // (distance, id)) are counted with a ballot and appended with one atomic per half-wave.
-                const float qnv = qts[r].x, tv = qts[r].y;
-                float dist[NJ]; bool pass[NJ]; uint64_t mask[NJ];
-                uint64_t any = 0;
+            const size_t row = q0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.nq) continue;
+            const float qnv = p.qn[row];
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                    pass[jj] = dist[jj] <= tv;                       // tau >= 0: same verdict before and after the clamp at 0
-                    mask[jj] = __ballot(pass[jj]);
-                    any |= mask[jj];
-                }
-                if (any == 0) continue;                              // wave-uniform: the common case in large batches
-                uint32_t hm[NJ];
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) hm[jj] = (uint32_t)(mask[jj] >> (lane & 32));
-                uint32_t tot = 0;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) tot += __popc(hm[jj]);
-                uint32_t base = 0;
-                if ((lane & 31) == 0 && tot) base = atomicAdd(&p.cand_cnt[row], tot);
-                base = __shfl(base, lane & 32);
-                const uint32_t below = (1u << (lane & 31)) - 1u;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    if (pass[jj]) {
-                        const uint32_t pos = base + __popc(hm[jj] & below);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj] < 0.f ? 0.f : dist[jj], (uint32_t)(p.nb_first + col[jj]));
-                    }
-                    base += __popc(hm[jj]);
-                }
-            } else if (row < p.nq) {
-                const float qnv = p.qn[row];
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    if (!col_ok[jj]) continue;
-                    float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                    dist = dist < 0.f ? 0.f : dist;
-                    p.slab[row * p.slab_ld + col[jj]] = dist;
-                }
+            for (int jj = 0; jj < NJ; ++jj) {
+                if (!col_ok[jj]) continue;
+                float dist = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
+                dist = dist < 0.f ? 0.f : dist;
+                p.slab[row * p.slab_ld + col[jj]] = dist;
             }
         }
     }
