@@ -310,18 +310,24 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = r8 + e;
-                uint32_t t0 = 0, t1 = 0;
+                uint64_t m[NJ], any = 0;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
                     const float dist = fmaf(-2.f, acc[i][jj][r], qts[e].x + bnv[jj]);
-                    const uint64_t m = __ballot(dist <= qts[e].y);       // tau >= 0: same verdict before and after the clamp at 0
-                    t0 += __builtin_popcount((uint32_t)m);
-                    t1 += __builtin_popcount((uint32_t)(m >> 32));
+                    m[jj] = __ballot(dist <= qts[e].y);                  // tau >= 0: same verdict before and after the clamp at 0
+                    any |= m[jj];
+                }
+                if (any == 0) continue;                                  // wave-uniform, and the common case in late chunks
+                uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    t0 += __builtin_popcount((uint32_t)m[jj]);
+                    t1 += __builtin_popcount((uint32_t)(m[jj] >> 32));
                 }
                 const int rho = 32 * i + (r & 3) + 8 * (r >> 2);         // local row of half 0; half 1 is 4 rows further
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(row_cnt) : "s"(t0), "n"(rho));
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(row_cnt) : "s"(t1), "n"(rho + 4));
-                hit[i] |= (uint32_t)((t0 | t1) != 0) << r;
+                hit[i] |= 1u << r;
             }
             }
         }
