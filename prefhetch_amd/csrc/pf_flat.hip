@@ -504,6 +504,44 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
             }
         });
     }
+    if (THREADS == 1024 && merge && nc <= 1024) {
+        // Few queries (wide workgroups; with 256 threads the 55 sort steps are cheaper).  Merge by enumeration: the state is sorted and keys are unique, so the final position of a key is its rank among
+        // the state (its index, or a binary search) plus the number of candidates below it -- counted with broadcast LDS
+        // reads, no barrier, no sort.  (c0 + nc) * nc comparisons over the workgroup: a few microseconds at the usual
+        // few hundred candidates, against 55 barrier-separated sort steps.
+        const uint32_t n = c0 + nc, total = n < k ? n : k;
+        for (uint32_t e = tid; e < n; e += THREADS) {
+            const uint64_t key = keys[e];
+            uint32_t rank = e;
+            if (e >= c0) {
+                uint32_t lo = 0, hi = c0;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+                rank = lo;
+            }
+            uint32_t j = 0;
+            for (; j + 4 <= nc; j += 4) {
+                const uint64_t a = keys[c0 + j], b = keys[c0 + j + 1], c = keys[c0 + j + 2], d = keys[c0 + j + 3];
+                rank += (a < key) + (b < key) + (c < key) + (d < key);
+            }
+            for (; j < nc; ++j) rank += keys[c0 + j] < key;
+            if (rank >= k) continue;
+            if (p.last) {
+                p.D[q * k + rank] = __uint_as_float((uint32_t)(key >> 32));
+                p.I[q * k + rank] = (int64_t)(uint32_t)key;
+            } else {
+                p.state[q * k + rank] = key;
+                if (rank == k - 1) p.tau[q] = __uint_as_float((uint32_t)(key >> 32));
+            }
+        }
+        if (p.last) {
+            for (uint32_t i = total + tid; i < k; i += THREADS) { p.D[q * k + i] = INFINITY; p.I[q * k + i] = -1; }
+        } else if (tid == 0) {
+            p.state_cnt[q] = total;
+            if (total < k) p.tau[q] = INFINITY;
+            p.cand_cnt[q] = 0;
+        }
+        return;
+    }
     // sort, keep k, carry or emit (a merge usually holds far fewer than SEL_CAP keys: sort only what is there)
     uint32_t n_sort = 64;
     while (n_sort < cnt) n_sort <<= 1;                          // cnt is stable: the scan ends with a barrier
