@@ -382,12 +382,18 @@ struct PassTw {
         if constexpr (PASS == 0) return const_load_tw(tw_ + table_index(kb, g));
         else return (tw_ + table_index(kb, g))[tb_ >> (G::a(PASS) + kb + 1)];   // uniform pointer + per-lane index
     }
+    // DESC: request the stages in the order a FORWARD pass consumes them (local bit NL-1 first: one twiddle, then two,
+    // four ...), so that the pass can start as soon as the first load is back; an inverse pass starts at local bit 0.
+    // [FROM, TO): the stages requested by this call, counted in consumption order -- the first two stages of a forward
+    // pass need three twiddles in all and can be asked for before the exchange even when registers are tight.
+    template <bool DESC = false, int FROM = 0, int TO = 99>
     PF_HD void load(const typename A::Tw *__restrict__ tw, int tid) {
         tw_ = tw;
         tb_ = PASS == 0 ? 0 : G::base(PASS, tid);                // pass 0: every twiddle is workgroup-uniform
         if constexpr (!LAZY) {
 #pragma unroll
-            for (int kb = 0; kb < NL; ++kb) {
+            for (int kk = (FROM < NL ? FROM : NL); kk < (TO < NL ? TO : NL); ++kk) {
+                const int kb = DESC ? NL - 1 - kk : kk;
 #pragma unroll
                 for (int g = 0; g < (G::R >> (kb + 1)); ++g) {
                     t[off(kb) + g] = fetch(kb, g);
@@ -650,22 +656,27 @@ PF_HD void exchange(typename A::V (&r)[G::R], typename A::V *lds, int tid, Sync 
 // ------------------------------------------------------------------------------------------------
 // Each pass's twiddles are requested before the exchange in front of it (when the register budget of the
 // arithmetic allows), so their latency overlaps the LDS round trip and the barriers.
-template <class G, class A, int WR, int RD, class Sync>
+template <class G, class A, int WR, int RD, bool HEAD_EARLY = false, class Sync>
 PF_HD void xchg_and_load(typename A::V (&r)[G::R], PassTw<G, A, RD> &t, const typename A::Tw *__restrict__ tw,
                          typename A::V *lds, int tid, Sync &&sync) {
     constexpr bool early = A::PREFETCH_TW && !Xchg<G, A>::HALF;   // at three workgroups per CU the registers go to occupancy instead
-    if constexpr (early) t.load(tw, tid);
+    constexpr bool fwd = WR < RD;                                  // forward transforms walk the passes upwards
+    // HEAD_EARLY (stand-alone forward transforms; measured: -4 % there, +2 % in the fused ct x pt kernel, which is tighter on
+    // registers): the first two stages' three twiddles are requested ahead of the exchange
+    constexpr int HEAD = (HEAD_EARLY && fwd && A::PREFETCH_TW) ? 2 : 0;
+    if constexpr (early) t.template load<fwd>(tw, tid);
+    else if constexpr (HEAD > 0) t.template load<fwd, 0, HEAD>(tw, tid);
     exchange<G, A, WR, RD>(r, lds, tid, sync);
-    if constexpr (!early) t.load(tw, tid);
+    if constexpr (!early) t.template load<fwd, HEAD>(tw, tid);
 }
 
-template <class G, class A, class Sync>
+template <class G, class A, bool HEAD_EARLY = false, class Sync>
 PF_HD void fwd_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
                    typename A::V *lds, int tid, Sync &&sync) {
-    { PassTw<G, A, 0> t0; t0.load(tw, tid); fwd_pass<G, A, 0>(r, ar, t0); }
-    if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 1>(r, ar, t); }
-    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 2>(r, ar, t); }
-    if constexpr (G::P >= 4) { PassTw<G, A, 3> t; xchg_and_load<G, A, 2, 3>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, t); }
+    { PassTw<G, A, 0> t0; t0.template load<true>(tw, tid); fwd_pass<G, A, 0>(r, ar, t0); }
+    if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 1>(r, ar, t); }
+    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 2>(r, ar, t); }
+    if constexpr (G::P >= 4) { PassTw<G, A, 3> t; xchg_and_load<G, A, 2, 3, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, t); }
 }
 
 // `tl` = twiddles of the first inverse pass (LAST), which the caller fetched ahead of time
@@ -756,7 +767,7 @@ PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, cons
                         uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0<G, A>(r, src, tid);
-    fwd_all<G, A>(r, ar, tw, lds, tid, sync);
+    fwd_all<G, A, true>(r, ar, tw, lds, tid, sync);
     canon_all<G, A>(r, ar);
     uint64_t o[G::R];
 #pragma unroll
@@ -770,7 +781,7 @@ PF_HD void body_ntt_fwd_mod(const A &ar, const typename A::Tw *__restrict__ tw, 
                             uint64_t q, uint64_t ratio1, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
     load_l0_mod<G, A>(r, src, tid, q, ratio1);
-    fwd_all<G, A>(r, ar, tw, lds, tid, sync);
+    fwd_all<G, A, true>(r, ar, tw, lds, tid, sync);
     canon_all<G, A>(r, ar);
     uint64_t o[G::R];
 #pragma unroll
@@ -840,7 +851,7 @@ PF_HD void body_ntt_fwd_from(const A &ar, const typename A::Tw *__restrict__ tw,
                              int tid, Sync &&sync) {
     typename A::V r[G::R];
     load(r, tid);
-    fwd_all<G, A>(r, ar, tw, lds, tid, sync);
+    fwd_all<G, A, true>(r, ar, tw, lds, tid, sync);
     canon_all<G, A>(r, ar);
     uint64_t o[G::R];
 #pragma unroll
