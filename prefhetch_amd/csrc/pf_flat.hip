@@ -17,8 +17,9 @@
 //              when it fills -- faiss ReservoirTopN does the same on the CPU for k >= 100).  This yields each
 //              query's running top-k and its k-th distance tau.
 //   streaming  the rest of the base is processed in geometrically growing chunks whose tile kernel FILTERS in its
-//              epilogue: only distances <= tau are appended (ballot + one atomic per half-wave) to the query's candidate
-//              list -- expected k * chunk / rows_seen survivors -- and k_select merges them into the running
+//              epilogue: only distances <= tau are appended to the query's candidate list (survivors counted with
+//              ballots, every row of a wave reserving its range in one atomic round trip; per workgroup through LDS
+//              when there are few queries) -- expected k * chunk / rows_seen survivors -- and k_select merges them into the running
 //              top-k and tightens tau.  No distance slab is written or re-read.  If a candidate list overflows
 //              (adversarial row order), k_select re-derives that query's chunk exactly by recomputing the
 //              distances with the same fmaf chain: slower, never wrong.
