@@ -140,7 +140,8 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
     }
 }
 
-// AGG: survivors are aggregated per row in LDS before the global append (few queries: the global counters are hot).
+// AGG (the 32- and 64-row geometries): survivors are aggregated per row in LDS before the global append -- with few
+// queries the global counters are hot, and a workgroup there spans 256 columns of every row.
 template <bool FILTER, class GEO, bool FAST, bool AGG = (GEO::TM <= 64)>
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
@@ -770,12 +771,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
             case 2: PF_TILE(false, GeoSmall64); break;
             case 3: PF_TILE(true, GeoSmall64); break;
             case 4: PF_TILE(false, GeoBatch); break;
-            default:
-                if (nq <= 512) {                       // up to four query tiles: aggregate per workgroup (32 more VGPRs, 3 waves/SIMD)
-                    if (fast) hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, true, true>), grid, dim3(256), 0, s, t);
-                    else hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, false, true>), grid, dim3(256), 0, s, t);
-                } else PF_TILE(true, GeoBatch);
-                break;
+            default: PF_TILE(true, GeoBatch); break;
         }
 #undef PF_TILE
     };
