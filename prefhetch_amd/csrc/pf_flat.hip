@@ -244,29 +244,38 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         // serialise on a handful of counters.  Survivors are first counted per row in LDS, then each row reserves its
         // range with ONE global atomic per workgroup, then the keys are written.
         uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sA) + 2 * TM, *s_base = s_cnt + TM;
-        auto verdict = [&](int i, int r, float (&dist)[NJ], bool (&pass)[NJ], uint32_t (&hm)[NJ]) {
-            const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float2 qt = *reinterpret_cast<const float2 *>(sA + 2 * lrow);
-            const float qnv = qt.x, tv = qt.y;
+        auto verdict = [&](int i, int r, float2 qt, float (&dist)[NJ], bool (&pass)[NJ], uint32_t (&hm)[NJ]) {
             uint32_t tot = 0;
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
-                dist[jj] = fmaf(-2.f, acc[i][jj][r], qnv + bnv[jj]);
-                pass[jj] = dist[jj] <= tv;
+                dist[jj] = fmaf(-2.f, acc[i][jj][r], qt.x + bnv[jj]);
+                pass[jj] = dist[jj] <= qt.y;
                 hm[jj] = (uint32_t)(__ballot(pass[jj]) >> (lane & 32));
                 tot += __popc(hm[jj]);
             }
             return tot;
         };
+        // (norm, threshold) pairs are fetched from LDS eight registers at a time: one exposed latency per batch
+        auto pairs = [&](int i, int r8, float2 (&qts)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                qts[e] = *reinterpret_cast<const float2 *>(sA + 2 * (wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)));
+        };
         uint32_t loc[MI][16];                                        // offset of this half-wave inside its row's range
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
-                const uint32_t tot = verdict(i, r, dist, pass, hm);
-                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                loc[i][r] = ((lane & 31) == 0 && tot) ? atomicAdd(&s_cnt[lrow], tot) : 0u;
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+                float2 qts[8];
+                pairs(i, r8, qts);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = r8 + e;
+                    float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
+                    const uint32_t tot = verdict(i, r, qts[e], dist, pass, hm);
+                    const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    loc[i][r] = ((lane & 31) == 0 && tot) ? atomicAdd(&s_cnt[lrow], tot) : 0u;
+                }
             }
         __syncthreads();
         if (tid < TM) { const uint32_t n = s_cnt[tid]; s_base[tid] = n ? atomicAdd(&p.cand_cnt[q0 + tid], n) : 0u; }
@@ -275,19 +284,25 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
-                if (__ballot(verdict(i, r, dist, pass, hm) != 0) == 0) continue;
-                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const size_t row = q0 + lrow;
-                uint32_t base = s_base[lrow] + __shfl(loc[i][r], lane & 32);
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+                float2 qts[8];
+                pairs(i, r8, qts);
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    if (pass[jj]) {
-                        const uint32_t pos = base + __popc(hm[jj] & below);
-                        if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj] < 0.f ? 0.f : dist[jj], (uint32_t)(p.nb_first + col[jj]));
+                for (int e = 0; e < 8; ++e) {
+                    const int r = r8 + e;
+                    float dist[NJ]; bool pass[NJ]; uint32_t hm[NJ];
+                    if (__ballot(verdict(i, r, qts[e], dist, pass, hm) != 0) == 0) continue;
+                    const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const size_t row = q0 + lrow;
+                    uint32_t base = s_base[lrow] + __shfl(loc[i][r], lane & 32);
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj) {
+                        if (pass[jj]) {
+                            const uint32_t pos = base + __popc(hm[jj] & below);
+                            if (pos < p.cap) p.cand[row * p.cap + pos] = make_key(dist[jj] < 0.f ? 0.f : dist[jj], (uint32_t)(p.nb_first + col[jj]));
+                        }
+                        base += __popc(hm[jj]);
                     }
-                    base += __popc(hm[jj]);
                 }
             }
         return;
