@@ -815,6 +815,8 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
         const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
         if (chunk > round_cols) chunk = chunk / round_cols * round_cols;
         if (chunk > f->nb - pos) chunk = f->nb - pos;
+        // a short tail is not worth a launch and a merge of its own (the 4x margin on the candidate capacity absorbs it)
+        if (geo != 2 && f->nb - pos - chunk < chunk / 2) chunk = f->nb - pos;
         t.nb_first = pos; t.nb_count = chunk;
         launch_tile(true, chunk);
         a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
