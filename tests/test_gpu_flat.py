@@ -227,3 +227,74 @@ def test_pack_rows_ntt_equals_pack_then_transform(N, qs, rows, force):
     two = pf.to_host_u64(ctx.ntt_forward_(ctx.pack_rows(flat, d_ids)))
     assert (fused == two).all()
     assert (fused == oracle.Oracle(N, qs).ntt_forward(oracle.pack_rows(base, ids, N, qs))).all()
+
+
+def test_step_captured_in_a_hip_graph(pf, capsys):
+    """include/prefhetch_hip.h promises that the polynomial calls and pf_flat_search (after pf_flat_reserve) neither
+    allocate nor synchronise: the whole step is captured into a hipGraph, replayed on fresh inputs and compared with the
+    oracle; the replay time of a single-query search (a chain of ~13 dependent launches) is printed beside the eager one."""
+    import time
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    N, qs = 4096, oracle.BFV_DEFAULT[4096][:2]
+    nb, nq, k = 60000, 3, 50
+    xb = _sift_like(rng, nb)
+    flat = pf.FlatL2(xb, dev)
+    flat.reserve(nq, k)
+    ctx = pf.RnsContext(N, qs, dev)
+    o = oracle.Oracle(N, qs)
+    xq = torch.empty((nq, 128), dtype=torch.float32, device=dev)
+    ct = torch.empty((2, 2, len(qs), N), dtype=torch.int64, device=dev)
+    pt = torch.empty((2, len(qs), N), dtype=torch.int64, device=dev)
+    out = torch.empty_like(ct)
+
+    def fresh():
+        hq = _sift_like(rng, nq)
+        hct = np.stack([np.stack([rng.integers(0, q, (2, N), dtype=np.uint64) for q in qs], axis=1) for _ in range(2)])
+        hpt = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)])
+        xq.copy_(torch.from_numpy(hq)); ct.copy_(pf.to_device_u64(hct, dev)); pt.copy_(pf.to_device_u64(hpt, dev))
+        return hq, hct, hpt
+
+    fresh()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):                       # warm-up outside capture (workspace, lazy module loads)
+        flat.search(xq, k)
+        ctx.ct_pt_mul(ct, pt, out=out)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        D, I = flat.search(xq, k)
+        ctx.ct_pt_mul(ct, pt, out=out)
+    for _ in range(3):
+        hq, hct, hpt = fresh()
+        graph.replay()
+        torch.cuda.synchronize()
+        Dr, Ir = oracle.flat_l2_search(xb, hq, k)
+        assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
+        assert (pf.to_host_u64(out) == o.ct_pt_mul(hct, hpt)).all()
+    # launch-bound case: one query against 1M rows, eager against replay
+    big = pf.FlatL2(_sift_like(rng, 1_000_000), dev)
+    big.reserve(1, 200)
+    q1 = torch.from_numpy(_sift_like(rng, 1)).to(dev)
+    with torch.cuda.stream(side):
+        big.search(q1, 200)
+    torch.cuda.synchronize()
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        D1, I1 = big.search(q1, 200)
+    De, Ie = big.search(q1, 200)
+    g1.replay()
+    torch.cuda.synchronize()
+    assert (I1 == Ie).all() and (D1 == De).all()
+
+    def ms(fn, reps=20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / reps
+
+    eager, replay = ms(lambda: big.search(q1, 200)), ms(g1.replay)
+    with capsys.disabled():
+        print(f"\n[hipGraph] single-query search over 1M x 128: eager {eager:.3f} ms, graph replay {replay:.3f} ms")
