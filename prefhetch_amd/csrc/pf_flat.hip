@@ -640,7 +640,7 @@ namespace {
 
 constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
 #ifndef PF_MAX_CHUNK
-#define PF_MAX_CHUNK 262144
+#define PF_MAX_CHUNK 524288
 #endif
 constexpr size_t MAX_CHUNK = PF_MAX_CHUNK; // largest streaming chunk (bounds the cost of one overflow rescan)
 
