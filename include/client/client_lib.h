@@ -19,6 +19,7 @@
 #include "client_server_utils.h"
 
 namespace wire { struct Transport; }
+namespace bfv { class Context; class Encryptor; class Decryptor; }
 
 const std::string server_addr = "http://localhost:8080/";     // reference :7 (used by HTTP transports)
 
@@ -60,6 +61,14 @@ void compute_nearest_coarse_vectors(const std::vector<float> &coarse_distance_sc
 
 // round 3: exact distances of the COARSE_PROBE best candidates, ranked on the client (reference :50-62)
 void get_precise_scores(const RankedLists &sorted_coarse_vectors, const QueryBatch &precise_query, PreciseScores &precise_scores);
+// Round 3 with the query ENCRYPTED -- the step the reference marks as TODO (reference :14, 28-30): the queries travel as
+// BFV ciphertexts of sum_i q_i X^i (route "precisesearch-encrypted", include/server/wire.h), the server multiplies them
+// with the packed candidate rows, the client decrypts the inner products and finishes ||q||^2 - 2 <q, x> + ||x||^2 with
+// the row norms the server returns.  Vector entries are rounded to integers by the encoding: on integer-valued data
+// (SIFT) the scores equal get_precise_scores' bit for bit.  `ctx` must use ring degree 8192 and SEAL's BFVDefault(8192)
+// data primes (bfv::Params::seal_default(8192, t)) with t above twice the largest inner product.
+void get_precise_scores_encrypted(const RankedLists &sorted_coarse_vectors, const QueryBatch &precise_query, const bfv::Context &ctx,
+                                  bfv::Encryptor &encryptor, bfv::Decryptor &decryptor, PreciseScores &precise_scores);
 void compute_nearest_precise_vectors(const PreciseScores &precise_scores, const RankedLists &sorted_coarse_vectors,
                                      PreciseRanking &nearest_precise_vectors);
 

@@ -73,6 +73,11 @@ class Server {
     void preciseSearchEncrypted(const uint64_t *query_ct_device /* [NQUERY][2][4][8192] */,
                                 const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &nearest_coarse_vector_idx,
                                 uint64_t *result_ct_device /* [NQUERY][ENC_POLYS_PER_QUERY][2][4][8192] */) const;
+    // The same with host buffers (what a transport has in hand): uploads the query ciphertexts, runs the device form,
+    // downloads the results, and returns ||x||^2 of every candidate row -- the client needs them to finish the distances
+    // ||q||^2 - 2 <q, x> + ||x||^2, and they do not depend on the query.
+    void preciseSearchEncryptedHost(const uint64_t *query_ct_host, const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &nearest_coarse_vector_idx,
+                                    uint64_t *result_ct_host, std::array<std::array<float, COARSE_PROBE>, NQUERY> &row_norms) const;
     // The executed flat-L2 shortlist of the protocol (client sort_nearest_centroids, src/client/client_lib.cpp:50-81)
     // on the server's IndexFlatL2 over the centroids: top-NPROBE centroid ids (and squared distances) per query.
     void nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,

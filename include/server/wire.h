@@ -13,6 +13,13 @@
 //   POST /precise-vector-pir  {"nearestPreciseVectorIndexes": [NQUERY][K]}
 //                             -> {"queryResults": [NQUERY][K][128]}                         (Query.cc:102-127)
 //
+// Added route (the encrypted form of /precisesearch, SURVEY.md 8(f-2): "then replace float arrays by serialized
+// ciphertexts"; the framing is this build's own, SEAL's save/load being unavailable):
+//   POST /precisesearch-encrypted  {"nearestCoarseVectorIndexes": [NQUERY][COARSE_PROBE],
+//                                   "queryCiphertexts": base64 of NQUERY x [2][4][8192] little-endian uint64}
+//                                  -> {"resultCiphertexts": base64 of NQUERY x ENC_POLYS_PER_QUERY x [2][4][8192] uint64,
+//                                      "rowNorms": [NQUERY][COARSE_PROBE]}
+//
 // A transport (Drogon in the reference, anything that moves a body) calls handle(); the client side
 // (include/client/client_lib.h) talks to a `Transport`, of which InProcessTransport is the one shipped here.
 // Error behaviour follows nlohmann's as the reference relies on it: malformed JSON -> wire::ParseError, a missing
@@ -58,11 +65,15 @@ void append_float(std::string &out, float v);
 void append_int(std::string &out, int64_t v);
 
 // The four routes.  `route` is the path without the leading slash: "query", "coarsesearch", "precisesearch",
-// "precise-vector-pir".  handle() dispatches; an unknown route throws std::out_of_range.
+// "precise-vector-pir", "precisesearch-encrypted".  handle() dispatches; an unknown route throws std::out_of_range.
 std::string handle_query(const Server &server);
 std::string handle_coarse_search(const Server &server, const std::string &body);
 std::string handle_precise_search(const Server &server, const std::string &body);
 std::string handle_precise_vector_pir(Server &server, const std::string &body);
+std::string handle_precise_search_encrypted(const Server &server, const std::string &body);
+// RFC 4648 base64 of raw bytes (ciphertext payloads)
+std::string base64_encode(const void *data, size_t bytes);
+std::vector<uint8_t> base64_decode(const std::string &text);      // ParseError on malformed input
 std::string handle(Server &server, const std::string &route, const std::string &body);
 
 // What the client needs from a connection: the body of GET <route> / POST <route>.

@@ -4,9 +4,11 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cmath>
 #include <cstdio>
 #include <stdexcept>
 
+#include "../../include/client/bfv.h"
 #include "../../include/prefhetch_hip.h"
 #include "../../include/server/wire.h"
 
@@ -192,6 +194,59 @@ void get_precise_scores(const std::array<std::vector<DistanceIndexData>, NQUERY>
     const wire::Json &scores = resp.at("preciseDistanceScores");
     for (size_t i = 0; i < (size_t)NQUERY; ++i)
         for (size_t j = 0; j < (size_t)COARSE_PROBE; ++j) precise_scores[i][j] = scores.at(i).at(j).as_float();
+}
+
+void get_precise_scores_encrypted(const RankedLists &sorted_coarse_vectors, const QueryBatch &precise_query, const bfv::Context &ctx,
+                                  bfv::Encryptor &encryptor, bfv::Decryptor &decryptor, PreciseScores &precise_scores) {
+    constexpr size_t D = (size_t)PRECISE_VECTOR_DIMENSIONS, NQ = (size_t)NQUERY, C = (size_t)COARSE_PROBE;
+    const size_t N = ctx.N(), L = ctx.L();
+    if (N != Server::ENC_RING_DEGREE || L != Server::ENC_LIMBS) throw std::invalid_argument("encrypted round: ring degree 8192 and 4 primes expected");
+    for (size_t l = 0; l < L; ++l)
+        if (ctx.params().moduli[l] != Server::ENC_MODULI[l]) throw std::invalid_argument("encrypted round: SEAL BFVDefault(8192) data primes expected");
+    std::array<std::array<faiss_idx_t, COARSE_PROBE>, NQUERY> ids;
+    for (size_t i = 0; i < NQ; ++i) {
+        if (sorted_coarse_vectors[i].size() < C) throw std::out_of_range("fewer than COARSE_PROBE coarse candidates");
+        for (size_t j = 0; j < C; ++j) ids[i][j] = sorted_coarse_vectors[i][j].idx;
+    }
+    // encode and encrypt
+    std::vector<uint64_t> plain(NQ * N);
+    for (size_t i = 0; i < NQ; ++i) bfv::encode_query(precise_query[i].data(), (uint32_t)D, (uint32_t)N, ctx.t(), plain.data() + i * N);
+    bfv::Ciphertexts qct;
+    encryptor.encrypt(plain.data(), NQ, qct);
+    std::vector<uint64_t> words(NQ * 2 * L * N);
+    qct.data.download(words.data(), words.size());
+    std::string body = "{\"nearestCoarseVectorIndexes\":";
+    append_id_matrix(body, ids);
+    body += ",\"queryCiphertexts\":\"";
+    body += wire::base64_encode(words.data(), words.size() * 8);
+    body += "\"}";
+    const wire::Json resp = wire::parse(transport().post("precisesearch-encrypted", body));
+    // decrypt the ENC_POLYS_PER_QUERY result ciphertexts of every query
+    const wire::Json &blob = resp.at("resultCiphertexts");
+    if (blob.kind != wire::Json::String) throw wire::TypeError("resultCiphertexts must be a base64 string");
+    const std::vector<uint8_t> raw = wire::base64_decode(blob.s);
+    const size_t blocks = NQ * Server::ENC_POLYS_PER_QUERY;
+    if (raw.size() != blocks * 2 * L * N * 8) throw std::out_of_range("resultCiphertexts has the wrong size");
+    bfv::Ciphertexts rct;
+    rct.count = blocks;
+    rct.data = bfv::DeviceWords(ctx.params().device, blocks * 2 * L * N);
+    rct.data.upload(reinterpret_cast<const uint64_t *>(raw.data()), blocks * 2 * L * N);
+    std::vector<uint64_t> rplain;
+    decryptor.decrypt(rct, rplain);
+    const wire::Json &norms = resp.at("rowNorms");
+    for (size_t i = 0; i < NQ; ++i) {
+        double qn = 0;
+        for (size_t k = 0; k < D; ++k) { const double v = (double)llrintf(precise_query[i][k]); qn += v * v; }
+        for (size_t b = 0; b < Server::ENC_POLYS_PER_QUERY; ++b) {
+            int64_t ip[Server::ENC_ROWS_PER_POLY];
+            bfv::decode_inner_products(rplain.data() + (i * Server::ENC_POLYS_PER_QUERY + b) * N, (uint32_t)D, Server::ENC_ROWS_PER_POLY, ctx.t(), ip);
+            for (size_t j = 0; j < Server::ENC_ROWS_PER_POLY; ++j) {
+                const size_t cand = b * Server::ENC_ROWS_PER_POLY + j;
+                if (cand >= C) break;
+                precise_scores[i][cand] = static_cast<float>(qn - 2.0 * (double)ip[j] + (double)norms.at(i).at(cand).as_float());
+            }
+        }
+    }
 }
 
 void compute_nearest_precise_vectors(const std::array<std::array<float, COARSE_PROBE>, NQUERY> &precise_scores,

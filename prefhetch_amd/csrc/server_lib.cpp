@@ -362,6 +362,30 @@ void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }
 
+void Server::preciseSearchEncryptedHost(const uint64_t *query_ct_host, const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &ids,
+                                        uint64_t *result_ct_host, std::array<std::array<float, COARSE_PROBE>, NQUERY> &row_norms) const {
+    if (!query_ct_host || !result_ct_host) throw std::invalid_argument("preciseSearchEncryptedHost: null buffer");
+    constexpr size_t ct_words = static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS * ENC_RING_DEGREE;
+    constexpr size_t out_words = ct_words * ENC_POLYS_PER_QUERY;
+    int dev = 0;
+    {
+        std::lock_guard<std::mutex> g(m_Impl->lock);
+        m_Impl->require_ready();
+        dev = m_Impl->device;
+    }
+    DevBuf d_in, d_res;                              // per call: the device form below takes the lock itself
+    d_in.reserve(dev, ct_words * 8);
+    d_res.reserve(dev, out_words * 8);
+    check(pf_memcpy_h2d(dev, d_in.ptr, query_ct_host, ct_words * 8, nullptr), "h2d");
+    check(pf_stream_synchronize(dev, nullptr), "sync");
+    preciseSearchEncrypted(static_cast<const uint64_t *>(d_in.ptr), ids, static_cast<uint64_t *>(d_res.ptr));
+    check(pf_memcpy_d2h(dev, result_ct_host, d_res.ptr, out_words * 8, nullptr), "d2h");
+    check(pf_stream_synchronize(dev, nullptr), "sync");
+    // ||x||^2 = the reference's distance chain against the zero vector (server_lib.cpp:151-162): same accumulation
+    const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> zero{};
+    preciseSearch(zero, ids, row_norms);
+}
+
 void Server::preciseVectorPIR(const std::array<std::array<faiss_idx_t, K>, NQUERY> &k_nearest_precise_vectors_idx,
                               std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY> &query_results) {
     Impl &im = *m_Impl;

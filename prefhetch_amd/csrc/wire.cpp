@@ -325,11 +325,86 @@ std::string handle_precise_vector_pir(Server &server, const std::string &body) {
     return out;
 }
 
+// ---- base64 ------------------------------------------------------------------------------------------
+std::string base64_encode(const void *data, size_t bytes) {
+    static const char tab[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    std::string out;
+    out.reserve((bytes + 2) / 3 * 4);
+    size_t i = 0;
+    for (; i + 3 <= bytes; i += 3) {
+        const uint32_t v = (uint32_t)p[i] << 16 | (uint32_t)p[i + 1] << 8 | p[i + 2];
+        out.push_back(tab[v >> 18]); out.push_back(tab[(v >> 12) & 63]); out.push_back(tab[(v >> 6) & 63]); out.push_back(tab[v & 63]);
+    }
+    if (i + 1 == bytes) {
+        const uint32_t v = (uint32_t)p[i] << 16;
+        out.push_back(tab[v >> 18]); out.push_back(tab[(v >> 12) & 63]); out += "==";
+    } else if (i + 2 == bytes) {
+        const uint32_t v = (uint32_t)p[i] << 16 | (uint32_t)p[i + 1] << 8;
+        out.push_back(tab[v >> 18]); out.push_back(tab[(v >> 12) & 63]); out.push_back(tab[(v >> 6) & 63]); out.push_back('=');
+    }
+    return out;
+}
+
+std::vector<uint8_t> base64_decode(const std::string &text) {
+    static int8_t rev[256];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 256; ++i) rev[i] = -1;
+        const char *tab = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; ++i) rev[(unsigned char)tab[i]] = (int8_t)i;
+        init = true;
+    }
+    if (text.size() % 4) throw ParseError("base64: length is not a multiple of 4");
+    std::vector<uint8_t> out;
+    out.reserve(text.size() / 4 * 3);
+    for (size_t i = 0; i < text.size(); i += 4) {
+        int v[4];
+        int pad = 0;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned char c = (unsigned char)text[i + k];
+            if (c == '=' && i + 4 == text.size() && k >= 2) { v[k] = 0; ++pad; continue; }
+            if (pad || rev[c] < 0) throw ParseError("base64: bad character at byte " + std::to_string(i + k));
+            v[k] = rev[c];
+        }
+        const uint32_t w = (uint32_t)v[0] << 18 | (uint32_t)v[1] << 12 | (uint32_t)v[2] << 6 | (uint32_t)v[3];
+        out.push_back((uint8_t)(w >> 16));
+        if (pad < 2) out.push_back((uint8_t)(w >> 8));
+        if (pad < 1) out.push_back((uint8_t)w);
+    }
+    return out;
+}
+
+std::string handle_precise_search_encrypted(const Server &server, const std::string &body) {
+    const Json req = parse(body);
+    std::array<std::array<faiss_idx_t, COARSE_PROBE>, NQUERY> ids;
+    read_ids(req.at("nearestCoarseVectorIndexes"), ids);
+    const Json &blob = req.at("queryCiphertexts");
+    if (blob.kind != Json::String) throw TypeError("queryCiphertexts must be a base64 string");
+    const std::vector<uint8_t> raw = base64_decode(blob.s);
+    constexpr size_t ct_words = static_cast<size_t>(NQUERY) * 2 * Server::ENC_LIMBS * Server::ENC_RING_DEGREE;
+    if (raw.size() != ct_words * 8) throw std::out_of_range("queryCiphertexts: expected " + std::to_string(ct_words * 8) + " bytes, got " + std::to_string(raw.size()));
+    std::vector<uint64_t> in(ct_words), out(ct_words * Server::ENC_POLYS_PER_QUERY);
+    std::memcpy(in.data(), raw.data(), raw.size());
+    std::array<std::array<float, COARSE_PROBE>, NQUERY> norms;
+    server.preciseSearchEncryptedHost(in.data(), ids, out.data(), norms);
+    std::string resp = "{\"resultCiphertexts\":\"";
+    resp += base64_encode(out.data(), out.size() * 8);
+    resp += "\",\"rowNorms\":[";
+    for (size_t q = 0; q < (size_t)NQUERY; ++q) {
+        if (q) resp.push_back(',');
+        write_float_row(resp, norms[q]);
+    }
+    resp += "]}";
+    return resp;
+}
+
 std::string handle(Server &server, const std::string &route, const std::string &body) {
     if (route == "query") return handle_query(server);
     if (route == "coarsesearch") return handle_coarse_search(server, body);
     if (route == "precisesearch") return handle_precise_search(server, body);
     if (route == "precise-vector-pir") return handle_precise_vector_pir(server, body);
+    if (route == "precisesearch-encrypted") return handle_precise_search_encrypted(server, body);
     throw std::out_of_range("no such route: " + route);
 }
 

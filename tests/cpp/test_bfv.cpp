@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../../include/client/bfv.h"
+#include "../../include/client/client_lib.h"
+#include "../../include/server/wire.h"
 #include "../../include/prefhetch_hip.h"
 #include "../../include/server/server_lib.h"
 
@@ -215,6 +217,28 @@ int main() {
             }
         }
         EXPECT(all_equal);
+
+        // ---- 3. the same round through the client library and the wire format: base64 ciphertexts in JSON ------
+        wire::InProcessTransport link(*srv);
+        set_transport(&link);
+        std::array<std::vector<DistanceIndexData>, NQUERY> ranked;
+        for (size_t i = 0; i < static_cast<size_t>(NQUERY); ++i)
+            for (size_t j = 0; j < static_cast<size_t>(COARSE_PROBE); ++j) ranked[i].push_back(DistanceIndexData{float(j), ids[i][j]});
+        std::array<std::array<float, COARSE_PROBE>, NQUERY> clear_scores, enc_scores;
+        get_precise_scores(ranked, query, clear_scores);                              // the reference's round 3, query in the clear
+        const size_t sent0 = link.bytes_sent, recv0 = link.bytes_received;
+        get_precise_scores_encrypted(ranked, query, ctx, enc, dec, enc_scores);        // the same round, query encrypted
+        EXPECT(std::memcmp(clear_scores.data(), plain_dist.data(), sizeof plain_dist) == 0);
+        EXPECT(std::memcmp(enc_scores.data(), plain_dist.data(), sizeof plain_dist) == 0);
+        std::printf("encrypted round over the wire format: %zu request bytes, %zu response bytes (plaintext round: %zu / %zu)\n",
+                    link.bytes_sent - sent0, link.bytes_received - recv0, sent0, recv0);
+        // base64 and malformed payloads
+        const uint8_t raw[5] = {0, 255, 16, 32, 7};
+        EXPECT(wire::base64_encode(raw, 5) == "AP8QIAc=" && wire::base64_decode("AP8QIAc=") == std::vector<uint8_t>(raw, raw + 5));
+        bool threw = false;
+        try { link.post("precisesearch-encrypted", "{\"nearestCoarseVectorIndexes\": [], \"queryCiphertexts\": \"AAAA\"}"); } catch (const std::out_of_range &) { threw = true; }
+        EXPECT(threw);
+        set_transport(nullptr);
     }
     if (fails) std::printf("test_bfv: %d FAILURES\n", fails);
     else std::printf("test_bfv: OK\n");

@@ -71,6 +71,22 @@ static int selftest() {
     s.clear();
     append_int(s, std::numeric_limits<int64_t>::min());
     EXPECT(parse(s).as_int() == std::numeric_limits<int64_t>::min());
+    // base64 (ciphertext payloads of the encrypted route): RFC 4648 vectors, every tail length, rejection of bad input
+    {
+        const char *plain[] = {"", "f", "fo", "foo", "foob", "fooba", "foobar"};
+        const char *enc[] = {"", "Zg==", "Zm8=", "Zm9v", "Zm9vYg==", "Zm9vYmE=", "Zm9vYmFy"};
+        for (int i = 0; i < 7; ++i) {
+            EXPECT(base64_encode(plain[i], std::strlen(plain[i])) == enc[i]);
+            const std::vector<uint8_t> back = base64_decode(enc[i]);
+            EXPECT(back.size() == std::strlen(plain[i]) && std::memcmp(back.data(), plain[i], back.size()) == 0);
+        }
+        std::vector<uint8_t> bytes(1000);
+        unsigned y = 99u;
+        for (auto &b : bytes) { y = y * 1664525u + 1013904223u; b = (uint8_t)(y >> 24); }
+        EXPECT(base64_decode(base64_encode(bytes.data(), bytes.size())) == bytes);
+        for (const char *bad : {"Zg=", "Z===", "Zm9v!A==", "=AAA", "Zg==Zg=="})
+            EXPECT(throws<ParseError>([&] { base64_decode(bad); }));
+    }
     // routes: an unknown route is refused before the server is touched
     { Server idle; EXPECT(throws<std::out_of_range>([&] { handle(idle, "nope", ""); })); }
     // client without a transport
