@@ -85,3 +85,34 @@ def test_random_moduli_parity(N, qs):
         assert (pf.to_host_u64(d_out) == o.ct_pt_mul(src, pt_ntt, flags, acc=acc0)).all(), flags
     a, b = ct[0], ct[1]
     assert (pf.to_host_u64(ctx.dyadic_mul(pf.to_device_u64(a, dev), pf.to_device_u64(b, dev))) == o.dyadic_mul(a, b)).all()
+
+
+KS_CASES = []
+for _N, _D in ((1024, 1), (2048, 3), (4096, 2), (8192, 5), (16384, 2), (32768, 3)):
+    _th = 44 if _N == 32768 else 45
+    for _hi in (_th, 56, 61):                       # one key-modulus set per arithmetic family
+        _qs = []
+        while len(_qs) < _D + 1:
+            _q = ntt_prime_below(1 << int(_rng.integers(max(30, _hi - 10), _hi + 1)), _N, _rng)
+            if _q not in _qs:
+                _qs.append(_q)
+        KS_CASES.append((_N, _qs))
+
+
+@pytest.mark.parametrize("N,qs", KS_CASES, ids=[f"N{n}-" + "-".join(str(q.bit_length()) for q in qs) for n, qs in KS_CASES])
+def test_random_moduli_key_switch(N, qs):
+    """pf_key_switch against the oracle for random key-modulus sets (last prime = special prime) of every family."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    K, D, B = len(qs), len(qs) - 1, 3
+    rng = np.random.default_rng(N * 7 + K)
+    o = oracle.Oracle(N, qs)
+    ctx = pf.RnsContext(N, qs, dev)
+    target = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs[:D]], axis=1)
+    target[0, :, 0] = np.array(qs[:D], dtype=np.uint64) - 1
+    target[1] = 0
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+    ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs[:D]], axis=2)
+    d_ct = pf.to_device_u64(ct, dev)
+    ctx.key_switch_(pf.to_device_u64(target, dev), pf.to_device_u64(ksk, dev), d_ct)
+    assert (pf.to_host_u64(d_ct) == o.key_switch(target, ksk, ct)).all()
