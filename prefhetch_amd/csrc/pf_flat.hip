@@ -471,6 +471,65 @@ __device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, ui
     }
 }
 
+// Bootstrap without sorting the whole chunk: the k-th smallest distance of the slab row is found by radix selection on
+// the fp32 bit pattern (distances are >= 0, so the bit patterns order like the values; four passes of a 256-bin LDS
+// histogram, most significant byte first), then everything below it and everything equal to it is collected -- the
+// caller's final sort of those few keys settles the order and, among equal distances, the smaller ids.  Returns false
+// (nothing touched) when the ties at the k-th distance would not fit the reservoir; the reservoir scan handles that.
+template <uint32_t THREADS>
+__device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, uint32_t *hist, uint32_t *ctl, uint32_t k, const float *row,
+                                                size_t nb_first, uint32_t n, int tid) {
+    constexpr int VPT = 8192 / THREADS;                              // the chunk (at most 8192 rows) lives in registers: one trip to memory
+    uint32_t u[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t col = tid + e * THREADS;
+        u[e] = col < n ? __float_as_uint(row[col]) : 0xFFFFFFFFu;    // the filler is above every distance (and above NaN patterns in use)
+    }
+    uint32_t prefix = 0, mask = 0, need = k;
+    for (int pass = 3; pass >= 0; --pass) {
+        for (uint32_t b = tid; b < 256; b += THREADS) hist[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VPT; ++e)
+            if (tid + e * THREADS < n && (u[e] & mask) == prefix) atomicAdd(&hist[(u[e] >> (8 * pass)) & 255u], 1u);
+        __syncthreads();
+        if (tid < 16) {                                              // 16 partial sums of 16 bins each
+            uint32_t sum = 0;
+            for (int b = 0; b < 16; ++b) sum += hist[tid * 16 + b];
+            ctl[4 + tid] = sum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0, g = 0;
+            while (g < 15 && cum + ctl[4 + g] < need) cum += ctl[4 + g++];
+            uint32_t b = g * 16;
+            while (b < g * 16 + 15 && cum + hist[b] < need) cum += hist[b++];
+            ctl[0] = prefix | (b << (8 * pass));
+            ctl[1] = need - cum;                                     // rank of the wanted element inside the chosen bin
+        }
+        __syncthreads();
+        prefix = ctl[0]; need = ctl[1]; mask |= 0xFFu << (8 * pass);
+        __syncthreads();
+    }
+    // prefix = bit pattern of the k-th smallest distance; count what is below / equal
+    if (tid == 0) { ctl[2] = 0; }
+    __syncthreads();
+    uint32_t take = 0;
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) take += (tid + e * THREADS < n) && u[e] <= prefix;
+    if (take) atomicAdd(&ctl[2], take);
+    __syncthreads();
+    if (ctl[2] > SEL_CAP) return false;                              // workgroup-uniform: a plateau of ties wider than the reservoir
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t col = tid + e * THREADS;
+        if (col < n && u[e] <= prefix) { const uint32_t pos = atomicAdd(&cnt, 1u); keys[pos] = ((uint64_t)u[e] << 32) | (uint32_t)(nb_first + col); }
+    }
+    __syncthreads();
+    return true;
+}
+
 // One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
 // running top-k, or -- if the candidate list overflowed -- rescan the chunk exactly.
 template <uint32_t THREADS>
@@ -493,7 +552,11 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
     }
     if (tid == 0) { cnt = merge ? c0 + nc : c0; tau = c0 == k ? p.state[q * k + k - 1] : KEY_INF; }
     __syncthreads();
-    if (p.mode == 0) {
+    __shared__ uint32_t hist[256], ctl[20];
+    bool done = false;
+    if (p.mode == 0 && c0 == 0 && p.nb_count > k && p.nb_count <= 8192)               // first chunk, more rows than results
+        done = radix_bootstrap<THREADS>(keys, cnt, hist, ctl, k, p.slab + q * (size_t)p.slab_ld, p.nb_first, (uint32_t)p.nb_count, tid);
+    if (p.mode == 0 && !done) {
         const float *row = p.slab + q * (size_t)p.slab_ld;
         const bool vec = (p.slab_ld & 3) == 0;
         reservoir_scan<THREADS>(keys, cnt, tau, k, p.nb_first, p.nb_count, tid, [&](size_t col, float (&v)[SEL_COLS]) {
@@ -506,7 +569,7 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
             }
             for (int e = 0; e < SEL_COLS; ++e) if (col + e < p.nb_count) v[e] = row[col + e];
         });
-    } else if (!merge) {
+    } else if (p.mode == 1 && !merge) {
         // overflow: the same k-ordered fmaf chain the matrix pipe evaluates, one base row at a time
         const float *x = p.xq + q * (size_t)p.d;
         const float qn = p.qn[q];
