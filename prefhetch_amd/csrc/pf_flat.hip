@@ -490,9 +490,18 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
     for (int pass = 3; pass >= 0; --pass) {
         for (uint32_t b = tid; b < 256; b += THREADS) hist[b] = 0;
         __syncthreads();
+        // the leading bytes of distances are nearly constant (same exponent): a thread adds runs of equal bins in one atomic
+        uint32_t run_bin = 0, run_len = 0;
 #pragma unroll
-        for (int e = 0; e < VPT; ++e)
-            if (tid + e * THREADS < n && (u[e] & mask) == prefix) atomicAdd(&hist[(u[e] >> (8 * pass)) & 255u], 1u);
+        for (int e = 0; e < VPT; ++e) {
+            if (tid + e * THREADS < n && (u[e] & mask) == prefix) {
+                const uint32_t b = (u[e] >> (8 * pass)) & 255u;
+                if (run_len && b != run_bin) { atomicAdd(&hist[run_bin], run_len); run_len = 0; }
+                run_bin = b;
+                ++run_len;
+            }
+        }
+        if (run_len) atomicAdd(&hist[run_bin], run_len);
         __syncthreads();
         if (tid < 16) {                                              // 16 partial sums of 16 bins each
             uint32_t sum = 0;
