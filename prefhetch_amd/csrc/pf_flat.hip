@@ -415,17 +415,52 @@ struct SelArgs {
     float *D; int64_t *I;                    // written when last
 };
 
-// in-LDS bitonic sort of the first n keys (n a power of two <= SEL_CAP; the rest must already be KEY_INF), ascending
+// in-LDS bitonic sort of the first n keys (n a power of two, 64 <= n <= SEL_CAP; the rest must already be KEY_INF), ascending.
+// The sort is bound by LDS traffic (four workgroups per CU run it at once), so the steps with stride 4, 2 and 1 of
+// every merge size -- and the sizes 2, 4, 8 entirely -- run on eight consecutive keys held in registers: one LDS round
+// trip for three steps (six for the three smallest sizes); 36 instead of 55 round trips at n = 1024.
 template <uint32_t THREADS>
 __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n = SEL_CAP) {
-    // Pair t of a step touches elements 2t - (t & (stride-1)) and + stride.  A wave always owns the same 64 consecutive
-    // pairs, which for stride <= 64 live in one aligned block of 128 elements: such steps only exchange data inside
-    // the wave (LDS operations of a wave execute in order) and need no workgroup barrier.
+    // register phase: thread t owns keys [8t, 8t+8); `first` runs the complete networks of sizes 2, 4, 8, otherwise the
+    // strides 4, 2, 1 of merge size `size` (>= 16: all eight keys of a thread then sort in the same direction)
+    auto in_registers = [&](uint32_t size, bool first) {
+        for (uint32_t t = tid; t < n / 8; t += THREADS) {
+            uint64_t v[8];
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(keys + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const ulonglong2 w = src[e]; v[2 * e] = w.x; v[2 * e + 1] = w.y; }
+            auto cx = [&](int i, int j, bool up) { const uint64_t a = v[i], b = v[j]; const bool sw = (a > b) == up; v[i] = sw ? b : a; v[j] = sw ? a : b; };
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) cx(i, i + 1, (i & 2) == 0);                                  // size 2
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (!(i & 2)) cx(i, i + 2, (i & 4) == 0);                       // size 4, stride 2
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) cx(i, i + 1, (i & 4) == 0);                                  // size 4, stride 1
+            }
+            const bool up = first ? ((8 * t) & 8u) == 0 : ((8 * t) & size) == 0;                            // size 8 / size `size`
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cx(i, i + 4, up);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (!(i & 2) && !(i & 4) ) { cx(i, i + 2, up); cx(i + 4, i + 6, up); }
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) cx(i, i + 1, up);
+            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(keys + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = make_ulonglong2(v[2 * e], v[2 * e + 1]);
+        }
+    };
     __syncthreads();
-    for (uint32_t size = 2; size <= n; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride > 64 || (stride == 64 && size > 128)) __syncthreads();
+    in_registers(8, true);
+    for (uint32_t size = 16; size <= n; size <<= 1) {
+        // Pair t of an LDS step touches elements 2t - (t & (stride-1)) and + stride.  A wave always owns the same 64
+        // consecutive pairs, which for stride <= 64 live in one aligned block of 128 elements: consecutive such steps
+        // only exchange data inside the wave (LDS operations of a wave execute in order) and need no workgroup barrier.
+        bool first_step = true;
+        for (uint32_t stride = size >> 1; stride >= 8; stride >>= 1) {
+            if (first_step || stride >= 64) __syncthreads();        // after a register phase, or data from other waves
             else __builtin_amdgcn_wave_barrier();
+            first_step = false;
             for (uint32_t t = tid; t < n / 2; t += THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));
                 const uint32_t hi = lo + stride;
@@ -434,6 +469,8 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int tid, uint32_t n
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
         }
+        __syncthreads();
+        in_registers(size, false);
     }
     __syncthreads();
 }
@@ -544,7 +581,7 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
 template <uint32_t THREADS>
 __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
     constexpr int SEL_COLS = SEL_ROUND / THREADS;
-    __shared__ uint64_t keys[SEL_CAP];
+    __shared__ __align__(16) uint64_t keys[SEL_CAP];
     __shared__ uint32_t cnt;
     __shared__ uint64_t tau;
     const int tid = threadIdx.x;
