@@ -12,12 +12,18 @@ value = encrypted queries/s over the whole step, all ranks (weak scaling: 1024 q
 base matrix and tables replicated).  Inputs are resident in HBM before the timed region.
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
-        N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        N > 1 is one process per GPU over torch.distributed (RCCL).  Launched as `python -m torch.distributed.run
+        --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` it joins that job; launched plainly it starts the
+        N rank processes itself (fresh children, before this process has touched a GPU) and exits with their code.
+        --single-process: the same step through the host-C++ device group (pf_multi_*: ONE process, one host thread +
+        stream per GPU, ncclCommInitAll + one in-place ncclAllGather) instead of torch.distributed.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,8 +51,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the two stages on separate HIP streams (matrix pipe vs FP64 VALU); per-stage times then overlap")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default min(16, cores))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: all host cores)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 through the C-ABI device group (pf_multi_*) in ONE process instead of one process per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip the figures outside the timed region (variants, encrypted round, PCIe)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as FRESH children of a process that has
+    not touched the GPU (no HIP call has happened yet: torch is imported, nothing else), one rank per GPU, rendezvous on
+    127.0.0.1.  Never an exec of this process."""
+    rehearsal = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1"
+    have = torch.cuda.device_count()                     # counts devices without initialising the runtime
+    if not rehearsal and have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this machine shows {have} HIP device(s) "
+                 "(PF_BENCH_SINGLE_DEVICE=1 PF_BENCH_BACKEND=gloo rehearses the control flow on one GPU)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 SEED = 20250801 + 3            # SURVEY.md 8(d): numpy PCG64, seed = 20250801 + config index
@@ -67,13 +94,23 @@ def make_inputs(rank, B, nb):
     return ct, pt, xb, xq
 
 
+def make_queries(rank, B):
+    """the query batch of `rank` alone (same stream as make_inputs)"""
+    rng = np.random.Generator(np.random.PCG64(SEED))
+    if rank:
+        rng = np.random.Generator(np.random.PCG64(SEED + 1000 * rank))
+        return rng.integers(0, 256, (B, DIM), dtype=np.uint8).astype(np.float32)
+    rng.integers(0, 256, (NB, DIM), dtype=np.uint8)
+    return rng.integers(0, 256, (B, DIM), dtype=np.uint8).astype(np.float32)
+
+
 def cpu_baseline(threads, ct, pt, xb, xq):
     """The oracle (CPU restatement of the SEAL/faiss algorithms; the reference itself cannot be built here)
     timed on the host cores on a bounded sample of the same workload (a slice of the buffers the GPU ran on):
     kind = "port"."""
     import oracle
     o = oracle.Oracle(N_RING, MODULI)
-    n_ct, n_q = min(1024, ct.shape[0]), min(64, xq.shape[0])
+    n_ct, n_q = min(1024, ct.shape[0]), min(256, xq.shape[0])
     ct, pt, xq = ct[:n_ct], pt[:n_ct], xq[:n_q]
     o.ct_pt_mul(ct[:32], pt[:32], threads=threads)                      # warm-up
     reps = []
@@ -82,17 +119,64 @@ def cpu_baseline(threads, ct, pt, xb, xq):
         o.ct_pt_mul(ct, pt, threads=threads)
         reps.append(time.perf_counter() - t0)
     t_ct = sorted(reps)[2] / n_ct
-    oracle.flat_l2_search(xb[:10000], xq, TOPK, threads=threads, f32=True)
-    t0 = time.perf_counter()
-    oracle.flat_l2_search(xb, xq, TOPK, threads=threads, f32=True)
-    t_q = (time.perf_counter() - t0) / n_q
+    # pre-filter as faiss runs it for nq >= 20: blocked |x|^2 + |y|^2 - 2 x.y with BLAS sgemm + per-query reservoir
+    oracle.flat_l2_search_blas(xb[:65536], xq, TOPK, threads=threads)
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.flat_l2_search_blas(xb, xq, TOPK, threads=threads)
+        reps.append(time.perf_counter() - t0)
+    t_q = sorted(reps)[1] / n_q
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max((p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"), default=None)
+    except Exception:
+        pass
     return {
         "value": 1.0 / (t_ct + t_q), "unit": "encrypted queries/s", "cores": threads, "kind": "port",
-        "sample": f"{n_ct} ct x pt (N=8192, 4 limbs, median of 5) + {n_q} flat-L2 queries vs {xb.shape[0]} x 128 (k=200), "
-                  f"OpenMP {threads} threads, same host buffers as the GPU run; restated CPU baseline (SEAL/faiss sources unavailable offline)",
-        "host_cores": os.cpu_count(),
+        "sample": f"{n_ct} ct x pt (N=8192, 4 limbs, median of 5) + {n_q} flat-L2 queries vs {xb.shape[0]} x 128 (k=200, median of 3; "
+                  f"BLAS sgemm blocks + reservoir as faiss does for nq >= 20), OpenMP {threads} threads (all host cores), "
+                  f"OpenBLAS {blas_threads} threads, same host buffers as the GPU run; restated CPU baseline (SEAL/faiss sources unavailable offline)",
+        "host_cores": os.cpu_count(), "blas_threads": blas_threads,
         "ctpt_only_qps": 1.0 / t_ct, "prefilter_only_qps": 1.0 / t_q,
     }
+
+
+def verify_outputs(out, D, I, h_ct, h_pt, h_xb, h_xq):
+    """The buffers the timed steps wrote, checked against the oracle after the timed region: ciphertexts 0..1 bit for bit,
+    (D, I) of queries 0..3 bit for bit (integer-valued data: every fp32 distance is exact)."""
+    import oracle
+    import prefhetch_amd as pf
+    exp = oracle.Oracle(N_RING, MODULI).ct_pt_mul(h_ct[:2], h_pt[:2])
+    ok_ct = bool((pf.to_host_u64(out[:2]) == exp).all())
+    Dr, Ir = oracle.flat_l2_search(h_xb, h_xq[:4], TOPK)
+    ok_flat = bool((I[:4].cpu().numpy() == Ir).all() and (D[:4].cpu().numpy() == Dr).all())
+    return ok_ct and ok_flat, {"ct_x_pt_first_2_bit_exact": ok_ct, "prefilter_first_4_bit_exact": ok_flat}
+
+
+def roofline_block(B, ms_b, sustained_ms=None):
+    # fused ct x pt kernel: read ct 2LN*8 + read pt LN*8 + write 2LN*8 = 40*L*N bytes per encrypted query
+    alg_bytes = 40 * LIMBS * N_RING * B
+    ach = alg_bytes / (ms_b * 1e-3) / 1e9
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath) and B == 1024:                     # the PMC record is for the default batch
+        try:
+            traffic = json.load(open(tpath)).get("k_ctpt_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, calibrated; not collected in this run)"
+        except Exception:
+            traffic = None
+    r = {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
+         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+         "traffic_source": traffic_source, "frac_of_measured_copy_6290": ach / 6290.0,
+         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_b,
+         "timing": "HIP events on the launch stream around the kernel inside the timed steps (interleaved with the pre-filter)"}
+    if sustained_ms:
+        r["sustained_ms"] = sustained_ms
+        r["sustained_frac"] = alg_bytes / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["sustained_note"] = "40 back-to-back launches of the same kernel after the timed region (device under continuous FP64 + HBM load)"
+    return r
 
 
 def main():
@@ -100,10 +184,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if args.single_process and args.gpus > 1:
+        if world > 1:
+            sys.exit("bench.py: --single-process is ONE process for all GPUs; do not start it under torch.distributed.run")
+        return main_group(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                  # does not return
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device; there is no CPU path")
     # PF_BENCH_SINGLE_DEVICE=1 + PF_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a one-GPU box
@@ -112,17 +199,21 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
+    dist, backend = None, None
+    if world > 1 or os.environ.get("PF_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: a one-rank job still goes through the collective
         import torch.distributed as dist
-        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
+        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")        # nccl == RCCL on ROCm
+        if "RANK" not in os.environ:                                 # one-rank job started plainly
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
     import prefhetch_amd as pf
-    from prefhetch_amd import dist as pfd
 
     B = args.batch
     h_ct, h_pt, h_xb, h_xq = make_inputs(rank, B, args.nb)            # generation and the one-time upload are untimed
@@ -131,13 +222,13 @@ def main():
     out = torch.empty_like(ct)
     xb = torch.from_numpy(h_xb).to(dev)
     xq = torch.from_numpy(h_xq).to(dev)
-    if rank or args.no_cpu_baseline or world > 1:
-        del h_ct, h_pt, h_xb, h_xq
     ctx = pf.RnsContext(N_RING, MODULI, dev)
     flat = pf.FlatL2(xb, dev)
     flat.reserve(B, TOPK)
     del xb
-    gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if world > 1 else None
+    # with a process group: the selection kernel writes this rank's packed block IN PLACE into `gathered`, then ONE all-gather
+    gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if dist else None
+    block = gathered[rank * B:(rank + 1) * B] if dist else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     side = torch.cuda.Stream(device=dev, priority=-1) if args.overlap else None     # high priority: its workgroups take the CU slots the matrix stage frees
@@ -149,40 +240,76 @@ def main():
             with torch.cuda.stream(side):
                 ctx.ct_pt_mul(ct, pt, out=out)
         if e: e[0].record()
-        D, I = flat.search(xq, TOPK)                               # stage A
+        if dist:                                                   # stage A, result emitted as the exchange record, in place
+            flat.search_packed(xq, TOPK, out=block)
+            D = I = None
+        else:
+            D, I = flat.search(xq, TOPK)                           # stage A
         if e: e[1].record()
         if side is None:
             ctx.ct_pt_mul(ct, pt, out=out)                         # stage B (one launch)
         else:
             torch.cuda.current_stream(dev).wait_stream(side)
         if e: e[2].record()
-        if world > 1:                                              # stage C: one collective, packed (I, D)
-            pfd.gather_topk(D, I, out=gathered)
+        if dist:                                                   # stage C: ONE collective (in place on RCCL)
+            dist.all_gather_into_tensor(gathered, block if backend == "nccl" else block.clone())
         if e: e[3].record()
         return D, I
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        D_last, I_last = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the buffers the timed steps wrote, against the oracle (rank 0; the oracle is the checker, never the thing measured)
+    verified, verified_detail = None, None
+    if rank == 0 and B >= 4:
+        if dist:
+            from prefhetch_amd import dist as pfd
+            D_chk, I_chk = pfd.unpack_topk(gathered[:4])
+        else:
+            D_chk, I_chk = D_last, I_last
+        verified, verified_detail = verify_outputs(out, D_chk, I_chk, h_ct, h_pt, h_xb, h_xq)
+        if dist and world > 1:                                     # another rank's block arrived intact: compare with a local search of its queries
+            other = world - 1
+            h_xq_o = make_queries(other, B)
+            Do, Io = flat.search(torch.from_numpy(h_xq_o[:4]).to(dev), TOPK)
+            Dg, Ig = pfd.unpack_topk(gathered[other * B:other * B + 4])
+            ok = bool(torch.equal(Ig, Io) and torch.equal(Dg.view(torch.int32), Do.view(torch.int32)))
+            verified_detail[f"gathered_block_of_rank_{other}_first_4_bit_exact"] = ok
+            verified = verified and ok
+
+    extras = rank == 0 and world == 1 and not args.no_extras
+    # sustained rate of the roofline kernel: back-to-back launches, nothing in between (device power management differs)
+    sustained_ms = None
+    if rank == 0 and world == 1:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(10):
+            ctx.ct_pt_mul(ct, pt, out=out)
+        a.record()
+        for _ in range(40):
+            ctx.ct_pt_mul(ct, pt, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        sustained_ms = a.elapsed_time(b) / 40
+
     # PCIe note (never part of `value`): one batch's ciphertexts + plaintexts host -> HBM and results back, pinned memory
     pcie = None
-    if rank == 0 and world == 1:
+    if extras:
         try:
             h_in = torch.empty(ct.numel() + pt.numel(), dtype=torch.int64).pin_memory()
             h_out = torch.empty(out.numel(), dtype=torch.int64).pin_memory()
@@ -199,7 +326,7 @@ def main():
 
     # SURVEY.md 8(d) also asks for k = 100 (the reference's K) and for N(0,1) data: extra figures, outside the timed region
     variants = None
-    if rank == 0 and world == 1:
+    if extras:
         def timed_search(index, q, k, reps=5):
             index.search(q, k)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,7 +348,7 @@ def main():
     # than derived): per query ceil(COARSE_PROBE * 128 / N) = 4 plaintext blocks of 64 candidate rows -> pack, forward
     # NTT of the plaintexts, ONE forward NTT of the query ciphertext, 4 fused dyadic + inverse-NTT products.
     enc_round = None
-    if rank == 0 and world == 1:
+    if extras:
         fan, rows = 4, N_RING // DIM
         ids = torch.full((B * fan, rows), -1, dtype=torch.int64, device=dev)
         gi = torch.Generator(device=dev).manual_seed(SEED)
@@ -267,18 +394,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         total_q = B * world
-        # fused ct x pt kernel: read ct 2LN*8 + read pt LN*8 + write 2LN*8 = 40*L*N bytes per encrypted query
-        alg_bytes = 40 * LIMBS * N_RING * B
-        ach = alg_bytes / (ms_b * 1e-3) / 1e9
         flops = 2.0 * B * args.nb * DIM
         tf = flops / (ms_a * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and B == 1024:                     # the PMC record is for the default batch
-            try:
-                traffic = json.load(open(tpath)).get("k_ctpt_bytes_per_launch")
-            except Exception:
-                traffic = None
         res = {
             "metric": "encrypted queries/sec at N=8192, 4 RNS limbs; NTT HBM GB/s vs roofline",
             "value": total_q / (elapsed / args.steps), "unit": "encrypted queries/s",
@@ -287,18 +404,16 @@ def main():
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": f"BASELINE config 3 per GPU: flat-L2 top-{TOPK} pre-filter of {B} queries over {args.nb} x {DIM} fp32 "
                                    f"+ fused ct x pt (N=8192, 4 limbs, batch {B}, coefficient form in and out)"
-                                   + (" + one RCCL all-gather of packed top-k" if world > 1 else ""),
+                                   + (f" + one all-gather ({backend}) of the packed top-k blocks" if dist else ""),
                        "ring_dim": N_RING, "limbs": LIMBS, "batch_per_gpu": B, "nb": args.nb, "dim": DIM, "k": TOPK,
-                       "parallelism": f"query-sharded x{world}, base matrix replicated"},
+                       "parallelism": f"query-sharded x{world}, base matrix replicated, one process per GPU (torch.distributed)"},
             "stages_ms": {"prefilter": ms_a, "ct_x_pt": ms_b, "gather": ms_c},
             "overlapped_streams": bool(args.overlap),
+            "verified": verified, "verified_detail": verified_detail,
             "ct_x_pt_only_qps_per_gpu": B / (ms_b * 1e-3),
             # protocol-level figure: ceil(COARSE_PROBE * 128 / N) = 4 ct x pt per reference query at N = 8192
             "reference_queries_per_s_at_4_ctpt_each": total_q / ((ms_a + 4 * ms_b + ms_c) * 1e-3),
-            "roofline": {"kernel": "k_ctpt<13,ArithF64,0> (fused NTT -> dyadic -> inverse NTT)", "bound": "hbm",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_of_measured_copy_6290": ach / 6290.0,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_b},
+            "roofline": roofline_block(B, ms_b, sustained_ms),
             "roofline_prefilter": {"kernel": "k_l2_tile (+ k_select), whole stage", "bound": "mfma", "achieved": tf,
                                    "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TF,
                                    "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b},
@@ -312,13 +427,75 @@ def main():
                 pcie["queries_per_s_if_inputs_and_outputs_crossed_pcie"] = B / ((ms_per_step + pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
             res["pcie_note"] = pcie
         if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            threads = args.cpu_threads or (os.cpu_count() or 1)
             res["cpu_baseline"] = cpu_baseline(threads, h_ct, h_pt, h_xb, h_xq)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_group(args):
+    """--single-process: the same step on G devices driven by ONE process through the C-ABI device group (pf_multi_*):
+    one host thread + stream per device, tables and base matrix replicated, queries / ciphertexts sharded, ONE in-place
+    all-gather (ncclAllGather after ncclCommInitAll; direct copies when PF_BENCH_SINGLE_DEVICE=1 lists cuda:0 G times)."""
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device; there is no CPU path")
+    import prefhetch_amd as pf
+    from prefhetch_amd import dist as pfd
+    G, B = args.gpus, args.batch
+    rehearsal = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1"
+    devices = [0] * G if rehearsal else list(range(G))
+    grp = pf.DeviceGroup(devices)
+    grp.ring(N_RING, MODULI)
+    xq, ct, pt, out, gathered = [], [], [], [], []
+    h0 = None
+    for r, d in enumerate(devices):
+        h_ct, h_pt, h_xb, h_xq = make_inputs(r, B, args.nb)
+        if r == 0:
+            grp.flat(h_xb)
+            grp.reserve(B, TOPK)
+            h0 = (h_ct, h_pt, h_xb, h_xq)
+        dev = torch.device("cuda", d)
+        xq.append(torch.from_numpy(h_xq).to(dev)); ct.append(pf.to_device_u64(h_ct, dev)); pt.append(pf.to_device_u64(h_pt, dev))
+        out.append(torch.empty_like(ct[-1]))
+        gathered.append(torch.empty((G * B, TOPK, 3), dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+
+    def step():
+        grp.flat_search(xq, TOPK, gathered)          # stage A on every member + the ONE exchange
+        grp.ct_pt_mul(ct, pt, out)                   # stage B on every member
+
+    for _ in range(args.warmup):
+        step()
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    grp.synchronize()
+    elapsed = time.perf_counter() - t0
+    verified, detail = None, None
+    if B >= 4:
+        D_chk, I_chk = pfd.unpack_topk(gathered[0][:4])
+        verified, detail = verify_outputs(out[0], D_chk, I_chk, *h0)
+        same = all(torch.equal(gathered[0].cpu(), g.cpu()) for g in gathered[1:])
+        detail["every_member_holds_the_same_gathered_buffer"] = bool(same)
+        verified = verified and same
+    res = {
+        "metric": "encrypted queries/sec at N=8192, 4 RNS limbs; NTT HBM GB/s vs roofline",
+        "value": G * B / (elapsed / args.steps), "unit": "encrypted queries/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 (exact-FP64 butterflies) + f32",
+        "data": "synthetic" + (" (REHEARSAL: every member on cuda:0, exchange by device-to-device copies)" if rehearsal else ""),
+        "config": {"workload": f"BASELINE config 3 per GPU: flat-L2 top-{TOPK} pre-filter of {B} queries over {args.nb} x {DIM} fp32 + fused ct x pt "
+                               f"(N=8192, 4 limbs, batch {B}) + one all-gather ({grp.exchange}) of the packed top-k blocks",
+                   "ring_dim": N_RING, "limbs": LIMBS, "batch_per_gpu": B, "nb": args.nb, "dim": DIM, "k": TOPK,
+                   "parallelism": f"query-sharded x{G}, base matrix replicated, ONE process: pf_multi_* device group (host thread + stream per GPU)"},
+        "verified": verified, "verified_detail": detail,
+    }
+    print(json.dumps(res), flush=True)
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -182,9 +182,56 @@ pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_h
 pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 
+/* pf_flat_search that also (or only: D and I may then be NULL) writes the exchange record of the multi-GPU gather,
+ * packed[q][i] = { uint32 id low word, uint32 id high word, uint32 distance bits }, 12 bytes per result, straight from
+ * the selection kernel -- the block a rank contributes to the ONE all-gather of SURVEY.md section 8(e) needs no packing
+ * pass.  The reference is single-device (/root/reference/src/server/server_lib.cpp:48-53) and has no counterpart. */
+pf_status pf_flat_search_packed(pf_flat *idx, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, uint32_t *packed,
+                                pf_stream stream);
+
 /* Bytes of scratch pf_flat_search needs for (nq, k); the library grows an internal workspace on
  * first use (outside graph capture) -- call pf_flat_reserve up front to keep searches allocation-free. */
 pf_status pf_flat_reserve(pf_flat *idx, size_t nq_max, uint32_t k_max);
+
+/* ---- device group: one process, G devices ------------------------------------------------ */
+/* The reference server is one process on one device (/root/reference/src/server/server_lib.cpp:48-53: one Drogon
+ * listener, one index).  A group extends that process to the G GPUs of a node: queries / ciphertexts are independent
+ * units, so the batch is split contiguously over the members (member r takes units [r*n_local, (r+1)*n_local)), the
+ * RNS tables and the fp32 base matrix are REPLICATED on every member, and the only exchange step is ONE all-gather of the
+ * packed per-member top-k blocks (RCCL over xGMI).  Every member has its own host thread and HIP stream; a group call
+ * hands the same job to all member threads, which enqueue on their streams and return -- nothing synchronises unless
+ * documented.  `exchange`: PF_MULTI_AUTO picks RCCL (ncclCommInitAll + ncclAllGather, librccl loaded on first use) when
+ * the devices are distinct and direct device-to-device copies when a device is listed more than once (RCCL refuses
+ * that; it is how a one-GPU machine rehearses the control flow).  PF_MULTI_PEER_COPY forces the copies
+ * (hipMemcpyPeerAsync pushes ordered by events), PF_MULTI_RCCL insists on RCCL. */
+typedef struct pf_multi pf_multi;
+enum { PF_MULTI_AUTO = 0, PF_MULTI_RCCL = 1, PF_MULTI_PEER_COPY = 2 };
+pf_status pf_multi_create(pf_multi **grp, const int *devices_host, int n_devices, int exchange);
+pf_status pf_multi_destroy(pf_multi *grp);
+/* exchange_out: PF_MULTI_RCCL or PF_MULTI_PEER_COPY, whichever the group uses.  Any out pointer may be NULL. */
+pf_status pf_multi_info(const pf_multi *grp, int *n_devices, int *devices_out_host, int *exchange_out);
+/* pf_ctx_create / pf_flat_create on every member (tables and base matrix replicated; xb_host is a HOST pointer).
+ * Blocking.  A second call replaces the first. */
+pf_status pf_multi_ring(pf_multi *grp, uint32_t N, uint32_t L, const uint64_t *moduli_host);
+pf_status pf_multi_flat(pf_multi *grp, const float *xb_host, size_t nb, uint32_t d);
+pf_status pf_multi_reserve(pf_multi *grp, size_t nq_local_max, uint32_t k_max);
+/* Member r's handles, for callers that own per-device buffers (any out pointer may be NULL; ctx / flat are NULL until
+ * pf_multi_ring / pf_multi_flat ran).  The handles belong to the group. */
+pf_status pf_multi_member(pf_multi *grp, int rank, int *device, pf_stream *stream, pf_ctx **ctx, pf_flat **flat);
+/* Device-resident search: xq_dev[r] = member r's shard [nq_local][d] on its device, gathered_dev[r] = member r's copy of
+ * the result [G * nq_local][k][3] uint32 (record layout of pf_flat_search_packed) on its device.  Member r's selection
+ * kernel writes its block in place at gathered_dev[r] + r * nq_local * k * 3, then ONE all-gather completes every copy.
+ * Enqueues and returns (pf_multi_synchronize waits). */
+pf_status pf_multi_flat_search(pf_multi *grp, const float *const *xq_dev, size_t nq_local, uint32_t k, uint32_t *const *gathered_dev);
+/* pf_ct_pt_mul on every member's shard: ct_dev[r] [B_local][2][L][N], pt_dev[r] [pt_count][L][N] (pt_count = B_local,
+ * or 1 to broadcast), out_dev[r] [B_local][2][L][N].  No exchange: the result ciphertexts go back to their clients. */
+pf_status pf_multi_ct_pt_mul(pf_multi *grp, const uint64_t *const *ct_dev, const uint64_t *const *pt_dev, size_t pt_count,
+                             uint64_t *const *out_dev, size_t B_local, int flags);
+pf_status pf_multi_synchronize(pf_multi *grp);
+/* What a host server calls (the shape of Server::preciseSearch's caller, /root/reference/src/server/controllers/Query.cc:65-98,
+ * at batch size): xq_host [nq][d] in host memory is sharded over the members (earlier members take the remainder),
+ * uploaded, searched, gathered, and member 0's copy comes back as D_host [nq][k] / I_host [nq][k].  Blocking. */
+pf_status pf_multi_flat_search_host(pf_multi *grp, const float *xq_host, size_t nq, uint32_t k, float *D_host, int64_t *I_host);
 
 #ifdef __cplusplus
 }

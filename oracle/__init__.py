@@ -71,6 +71,8 @@ def lib():
         L.pfo_gather_rows.argtypes = [f32p, i64p, C.c_size_t, C.c_size_t, f32p]
         L.pfo_flat_l2_search.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, f32p, i64p, C.c_int, C.c_int]
         L.pfo_flat_l2_search_f32.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, f32p, i64p, C.c_int]
+        L.pfo_l2_reservoir_block.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p, C.c_int64, C.c_size_t, C.c_size_t,
+                                             f32p, i64p, C.POINTER(C.c_uint32), f32p, C.c_int, f32p, i64p, C.c_int]
         L.pfo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -230,6 +232,38 @@ def flat_l2_search(xb, xq, k, mode=0, threads=0, f32=False):
         lib().pfo_flat_l2_search_f32(_p(xb, C.c_float), xb.shape[0], xb.shape[1], _p(xq, C.c_float), nq, k, _p(D, C.c_float), _p(I, C.c_int64), threads)
     else:
         lib().pfo_flat_l2_search(_p(xb, C.c_float), xb.shape[0], xb.shape[1], _p(xq, C.c_float), nq, k, _p(D, C.c_float), _p(I, C.c_int64), mode, threads)
+    return D, I
+
+
+def flat_l2_search_blas(xb, xq, k, threads=0, block=32768):
+    """faiss IndexFlatL2::search as it runs for nq >= 20 (exhaustive_L2sqr_blas): blocks of the base matrix, inner
+    products by BLAS sgemm (numpy's OpenBLAS, its own thread pool), dist = |x|^2 + |y|^2 - 2 x.y, per-query reservoir
+    (ReservoirTopN) cut back by quickselect -- the CPU baseline of the pre-filter.  fp32 throughout, so distances carry
+    the cancellation error of the expansion (exact on SIFT-like integer data up to 2^24)."""
+    xb = np.ascontiguousarray(xb, np.float32)
+    xq = np.ascontiguousarray(xq, np.float32)
+    nq, nb = xq.shape[0], xb.shape[0]
+    qn = np.einsum("ij,ij->i", xq, xq).astype(np.float32)
+    cap = max(2 * k, 256)
+    res_d = np.empty((nq, cap), np.float32)
+    res_i = np.empty((nq, cap), np.int64)
+    cnt = np.zeros(nq, np.uint32)
+    thr = np.full(nq, np.inf, np.float32)
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    ip = np.empty((nq, block), np.float32)
+    if nb == 0:
+        D[:] = np.inf
+        I[:] = -1
+        return D, I
+    for lo in range(0, nb, block):
+        blk = xb[lo:lo + block]
+        n = blk.shape[0]
+        bn = np.einsum("ij,ij->i", blk, blk).astype(np.float32)
+        np.matmul(xq, blk.T, out=ip[:, :n])
+        lib().pfo_l2_reservoir_block(_p(ip, C.c_float), nq, n, block, _p(qn, C.c_float), _p(bn, C.c_float), lo, k, cap,
+                                     _p(res_d, C.c_float), _p(res_i, C.c_int64), _p(cnt, C.c_uint32), _p(thr, C.c_float),
+                                     int(lo + n >= nb), _p(D, C.c_float), _p(I, C.c_int64), threads)
     return D, I
 
 

@@ -499,6 +499,69 @@ void pfo_flat_l2_search_f32(const float *xb, size_t nb, size_t d, const float *x
     }
 }
 
+/* faiss's exhaustive_L2sqr_blas + ReservoirTopN (what IndexFlatL2::search runs for nq >= 20), selection half, for the
+ * cpu_baseline timing: the caller computes ip = xq . xb_block^T with BLAS sgemm (numpy's OpenBLAS) and this routine folds
+ * the block into every query's reservoir: dist = |x|^2 + |y|^2 - 2 x.y, kept when below the query's threshold; a full
+ * reservoir (capacity cap >= 2k) is cut back to its k smallest (quickselect) and the threshold tightened.
+ * res_d / res_i [nq][cap], res_cnt / thr [nq] persist across blocks (thr starts at +inf, res_cnt at 0).
+ * finish = 1 additionally sorts each reservoir (distance, then id) and writes the k best to D / I. */
+static void pfo_hit_select(pfo_hit *h, size_t n, size_t k) {          /* k smallest of h[0..n) to the front */
+    size_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const pfo_hit pv = h[lo + (hi - lo) / 2];
+        size_t i = lo, j = hi - 1;
+        while (i <= j) {
+            while (hit_cmp(&h[i], &pv) < 0) i++;
+            while (hit_cmp(&h[j], &pv) > 0) { if (j == 0) break; j--; }
+            if (i <= j) { pfo_hit t = h[i]; h[i] = h[j]; h[j] = t; i++; if (j == 0) break; j--; }
+        }
+        if (k <= j + 1 && j + 1 > lo && j + 1 < hi) hi = j + 1;
+        else if (k >= i && i > lo) lo = i;
+        else if (k > j + 1 && k < i) return;                            /* the split point falls between the partitions */
+        else { qsort(h + lo, hi - lo, sizeof(pfo_hit), hit_cmp); return; }   /* degenerate pivot: finish directly */
+    }
+}
+
+void pfo_l2_reservoir_block(const float *ip, size_t nq, size_t nblk, size_t ld, const float *qn, const float *bn, int64_t id0,
+                            size_t k, size_t cap, float *res_d, int64_t *res_i, uint32_t *res_cnt, float *thr, int finish,
+                            float *D, int64_t *I, int nthreads) {
+    int nt = clamp_threads(nthreads); (void)nt;
+    PAR_FOR
+    for (long q = 0; q < (long)nq; q++) {
+        float *rd = res_d + (size_t)q * cap; int64_t *ri = res_i + (size_t)q * cap;
+        size_t cnt = res_cnt[q];
+        float t = thr[q];
+        const float *row = ip + (size_t)q * ld;
+        const float nq2 = qn[q];
+        for (size_t j = 0; j < nblk; j++) {
+            float dist = nq2 + bn[j] - 2.f * row[j];
+            if (dist < 0.f) dist = 0.f;
+            if (!(dist < t)) continue;
+            rd[cnt] = dist; ri[cnt] = id0 + (int64_t)j; cnt++;
+            if (cnt == cap) {
+                pfo_hit *h = (pfo_hit *)malloc(sizeof(pfo_hit) * cap);
+                for (size_t e = 0; e < cap; e++) { h[e].dis = rd[e]; h[e].id = ri[e]; }
+                pfo_hit_select(h, cap, k);
+                float mx = 0.f;
+                for (size_t e = 0; e < k; e++) { rd[e] = h[e].dis; ri[e] = h[e].id; if (h[e].dis > mx) mx = h[e].dis; }
+                free(h);
+                cnt = k; t = mx;          /* keep ties with the k-th out: ids ascend, later ones lose the tie anyway */
+            }
+        }
+        res_cnt[q] = (uint32_t)cnt; thr[q] = t;
+        if (finish) {
+            pfo_hit *h = (pfo_hit *)malloc(sizeof(pfo_hit) * (cnt ? cnt : 1));
+            for (size_t e = 0; e < cnt; e++) { h[e].dis = rd[e]; h[e].id = ri[e]; }
+            qsort(h, cnt, sizeof(pfo_hit), hit_cmp);
+            for (size_t e = 0; e < k; e++) {
+                if (e < cnt) { D[(size_t)q * k + e] = h[e].dis; I[(size_t)q * k + e] = h[e].id; }
+                else { D[(size_t)q * k + e] = INFINITY; I[(size_t)q * k + e] = -1; }
+            }
+            free(h);
+        }
+    }
+}
+
 int pfo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

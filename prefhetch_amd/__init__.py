@@ -5,4 +5,4 @@ it (include/server/server_lib.h).  This package is the Python-side harness over 
 importing it loads the HIP library and fails loudly if that is missing -- there is no CPU fallback.
 """
 from ._lib import LIB_PATH, PfError, SYMBOLS, lib  # noqa: F401
-from .api import ACCUMULATE, IN_NTT, OUT_NTT, FlatL2, IvfPq, RnsContext, to_device_u64, to_host_u64  # noqa: F401
+from .api import ACCUMULATE, IN_NTT, OUT_NTT, DeviceGroup, FlatL2, IvfPq, RnsContext, to_device_u64, to_host_u64  # noqa: F401

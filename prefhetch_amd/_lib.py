@@ -17,7 +17,9 @@ SYMBOLS = [
     "pf_ntt_forward", "pf_ntt_inverse", "pf_ntt_forward_to", "pf_ntt_inverse_to", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
     "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_key_switch", "pf_pack_rows", "pf_pack_rows_ntt",
     "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
-    "pf_flat_reserve",
+    "pf_flat_reserve", "pf_flat_search_packed",
+    "pf_multi_create", "pf_multi_destroy", "pf_multi_info", "pf_multi_ring", "pf_multi_flat", "pf_multi_reserve", "pf_multi_member",
+    "pf_multi_flat_search", "pf_multi_ct_pt_mul", "pf_multi_synchronize", "pf_multi_flat_search_host",
     "pf_ivfpq_create", "pf_ivfpq_destroy", "pf_ivfpq_add_encoded", "pf_ivfpq_info", "pf_ivfpq_get_list", "pf_ivfpq_search_lists",
 ]
 
@@ -70,6 +72,18 @@ def _load():
     lib.pf_l2_gathered.argtypes = [vp, vp, vp, sz, u32, vp, vp]
     lib.pf_gather_rows.argtypes = [vp, vp, sz, vp, vp]
     lib.pf_flat_reserve.argtypes = [vp, sz, u32]
+    lib.pf_flat_search_packed.argtypes = [vp, vp, sz, u32, vp, vp, vp, vp]
+    lib.pf_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), i32, i32]
+    lib.pf_multi_destroy.argtypes = [vp]
+    lib.pf_multi_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pf_multi_ring.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
+    lib.pf_multi_flat.argtypes = [vp, vp, sz, u32]
+    lib.pf_multi_reserve.argtypes = [vp, sz, u32]
+    lib.pf_multi_member.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.pf_multi_flat_search.argtypes = [vp, C.POINTER(vp), sz, u32, C.POINTER(vp)]
+    lib.pf_multi_ct_pt_mul.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(vp), sz, i32]
+    lib.pf_multi_synchronize.argtypes = [vp]
+    lib.pf_multi_flat_search_host.argtypes = [vp, vp, sz, u32, vp, vp]
     lib.pf_ivfpq_create.argtypes = [C.POINTER(vp), i32, u32, u32, u32, vp, vp]
     lib.pf_ivfpq_destroy.argtypes = [vp]
     lib.pf_ivfpq_add_encoded.argtypes = [vp, sz, vp, vp, vp]

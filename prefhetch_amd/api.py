@@ -230,6 +230,22 @@ class FlatL2:
         check(lib.pf_flat_search(self._h, pq, nq, k, C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()), _stream(self.device)), "pf_flat_search")
         return D, I
 
+    def search_packed(self, xq, k, out=None):
+        """The same search, emitting the exchange record of the multi-GPU gather instead of (D, I): int32 [nq, k, 3] =
+        (id low word, id high word, distance bits), written by the selection kernel itself.  `out` may be a view into a
+        larger gathered buffer (this rank's block), so that the all-gather runs in place."""
+        pq = _req(xq, torch.float32, self.device_index, "xq")
+        if xq.dim() != 2 or xq.shape[1] != self.d:
+            raise ValueError("xq must be [nq, d]")
+        nq = xq.shape[0]
+        if out is None:
+            out = torch.empty((nq, k, 3), dtype=torch.int32, device=self.device)
+        po = _req(out, torch.int32, self.device_index, "out")
+        if out.numel() != nq * k * 3:
+            raise ValueError("out must hold nq * k * 3 int32 words")
+        check(lib.pf_flat_search_packed(self._h, pq, nq, k, None, None, po, _stream(self.device)), "pf_flat_search_packed")
+        return out
+
     def l2_gathered(self, xq, ids):
         pq = _req(xq, torch.float32, self.device_index, "xq")
         pi = _req(ids, torch.int64, self.device_index, "ids")
@@ -245,6 +261,85 @@ class FlatL2:
         out = torch.empty(tuple(ids.shape) + (self.d,), dtype=torch.float32, device=self.device)
         check(lib.pf_gather_rows(self._h, pi, ids.numel(), C.c_void_p(out.data_ptr()), _stream(self.device)), "pf_gather_rows")
         return out
+
+
+class DeviceGroup:
+    """pf_multi_*: ONE process driving G devices, one host thread + stream per device, batch sharded contiguously, RNS
+    tables and base matrix replicated, one all-gather (RCCL, or direct copies when a device is listed twice) of the
+    packed top-k blocks.  SURVEY.md section 8(e); the reference is single-device (src/server/server_lib.cpp:48-53)."""
+    AUTO, RCCL, PEER_COPY = 0, 1, 2
+
+    def __init__(self, devices, exchange=0):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        check(lib.pf_multi_create(C.byref(h), arr, len(self.devices), int(exchange)), "pf_multi_create")
+        self._h = h
+        ex = C.c_int()
+        check(lib.pf_multi_info(self._h, None, None, C.byref(ex)), "pf_multi_info")
+        self.exchange = "rccl" if ex.value == self.RCCL else "peer_copy"
+        self.G = len(self.devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pf_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def ring(self, N, moduli):
+        self.N, self.L = int(N), len(moduli)
+        arr = (C.c_uint64 * len(moduli))(*[int(q) for q in moduli])
+        check(lib.pf_multi_ring(self._h, int(N), len(moduli), arr), "pf_multi_ring")
+
+    def flat(self, xb_host):
+        xb = np.ascontiguousarray(xb_host, dtype=np.float32)
+        self.nb, self.d = xb.shape
+        check(lib.pf_multi_flat(self._h, xb.ctypes.data_as(C.c_void_p), xb.shape[0], xb.shape[1]), "pf_multi_flat")
+
+    def reserve(self, nq_local_max, k_max):
+        check(lib.pf_multi_reserve(self._h, int(nq_local_max), int(k_max)), "pf_multi_reserve")
+
+    def stream(self, rank):
+        """member `rank`'s hipStream_t as a torch ExternalStream (for events and for ordering caller-side work)"""
+        s = C.c_void_p()
+        check(lib.pf_multi_member(self._h, rank, None, C.byref(s), None, None), "pf_multi_member")
+        return torch.cuda.ExternalStream(s.value, device=torch.device("cuda", self.devices[rank]))
+
+    def _ptrs(self, tensors, dtype, name):
+        if len(tensors) != self.G:
+            raise ValueError(f"{name}: need one tensor per member")
+        return (C.c_void_p * self.G)(*[_req(t, dtype, self.devices[r], f"{name}[{r}]").value for r, t in enumerate(tensors)])
+
+    def flat_search(self, xq, k, gathered):
+        """xq[r]: [nq_local, d] float32 on member r's device; gathered[r]: int32 [G * nq_local, k, 3] on member r's device."""
+        nq_local = xq[0].shape[0]
+        if any(t.shape != (nq_local, self.d) for t in xq) or any(t.numel() != self.G * nq_local * k * 3 for t in gathered):
+            raise ValueError("flat_search: shards must be [nq_local, d] and gathered buffers [G * nq_local, k, 3]")
+        check(lib.pf_multi_flat_search(self._h, self._ptrs(xq, torch.float32, "xq"), nq_local, k, self._ptrs(gathered, torch.int32, "gathered")),
+              "pf_multi_flat_search")
+
+    def ct_pt_mul(self, ct, pt, out, flags=0):
+        per_ct = 2 * self.L * self.N
+        B_local = ct[0].numel() // per_ct
+        pt_count = pt[0].numel() // (self.L * self.N)
+        if pt_count not in (1, B_local) or any(t.numel() != B_local * per_ct for t in list(ct) + list(out)):
+            raise ValueError("ct_pt_mul: every member needs [B_local, 2, L, N] ct / out and 1 or B_local plaintexts")
+        check(lib.pf_multi_ct_pt_mul(self._h, self._ptrs(ct, torch.int64, "ct"), self._ptrs(pt, torch.int64, "pt"), pt_count,
+                                     self._ptrs(out, torch.int64, "out"), B_local, int(flags)), "pf_multi_ct_pt_mul")
+
+    def synchronize(self):
+        check(lib.pf_multi_synchronize(self._h), "pf_multi_synchronize")
+
+    def flat_search_host(self, xq_host, k):
+        """host [nq, d] float32 -> host (D [nq, k] float32, I [nq, k] int64): shard, upload, search, ONE all-gather, download."""
+        xq = np.ascontiguousarray(xq_host, dtype=np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        check(lib.pf_multi_flat_search_host(self._h, xq.ctypes.data_as(C.c_void_p), nq, k, D.ctypes.data_as(C.c_void_p),
+                                            I.ctypes.data_as(C.c_void_p)), "pf_multi_flat_search_host")
+        return D, I
 
 
 class IvfPq:

@@ -412,8 +412,18 @@ struct SelArgs {
     const float *xq, *xb, *qn, *bn; uint32_t d;                // mode 1 overflow fallback: exact recomputation
     uint32_t k;
     int mode, first, last;
-    float *D; int64_t *I;                    // written when last
+    float *D; int64_t *I;                    // written when last (either may be null)
+    uint32_t *packed;                        // written when last, if not null: [nq][k]{id low word, id high word, distance bits}
 };
+
+// final results of one query position: the caller's (D, I) and / or the 12-byte exchange record of the multi-GPU gather
+__device__ __forceinline__ void emit_result(const SelArgs &p, size_t pos, bool ok, uint64_t key) {
+    const uint32_t dbits = ok ? (uint32_t)(key >> 32) : 0x7F800000u;            // +inf
+    const int64_t id = ok ? (int64_t)(uint32_t)key : -1;
+    if (p.D) p.D[pos] = __uint_as_float(dbits);
+    if (p.I) p.I[pos] = id;
+    if (p.packed) { uint32_t *r = p.packed + 3 * pos; r[0] = (uint32_t)id; r[1] = (uint32_t)((uint64_t)id >> 32); r[2] = dbits; }
+}
 
 // in-LDS bitonic sort of the first n keys (n a power of two, 64 <= n <= SEL_CAP; the rest must already be KEY_INF), ascending.
 // The sort is bound by LDS traffic (four workgroups per CU run it at once), so the steps with stride 4, 2 and 1 of
@@ -652,15 +662,14 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
             for (; j < nc; ++j) rank += keys[c0 + j] < key;
             if (rank >= k) continue;
             if (p.last) {
-                p.D[q * k + rank] = __uint_as_float((uint32_t)(key >> 32));
-                p.I[q * k + rank] = (int64_t)(uint32_t)key;
+                emit_result(p, q * k + rank, true, key);
             } else {
                 p.state[q * k + rank] = key;
                 if (rank == k - 1) p.tau[q] = __uint_as_float((uint32_t)(key >> 32));
             }
         }
         if (p.last) {
-            for (uint32_t i = total + tid; i < k; i += THREADS) { p.D[q * k + i] = INFINITY; p.I[q * k + i] = -1; }
+            for (uint32_t i = total + tid; i < k; i += THREADS) emit_result(p, q * k + i, false, 0);
         } else if (tid == 0) {
             p.state_cnt[q] = total;
             if (total < k) p.tau[q] = INFINITY;
@@ -674,12 +683,7 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
     bitonic_sort<THREADS>(keys, tid, n_sort);
     const uint32_t total = cnt < k ? cnt : k;
     if (p.last) {
-        for (uint32_t i = tid; i < k; i += THREADS) {
-            const uint64_t key = keys[i];
-            const bool ok = i < total;
-            p.D[q * k + i] = ok ? __uint_as_float((uint32_t)(key >> 32)) : INFINITY;
-            p.I[q * k + i] = ok ? (int64_t)(uint32_t)key : -1;
-        }
+        for (uint32_t i = tid; i < k; i += THREADS) emit_result(p, q * k + i, i < total, keys[i]);
     } else {
         for (uint32_t i = tid; i < total; i += THREADS) p.state[q * k + i] = keys[i];
         if (tid == 0) {
@@ -853,9 +857,14 @@ pf_status pf_flat_reserve(pf_flat *f, size_t nq_max, uint32_t k_max) {
 }
 
 pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream) {
+    if (nq && (!D || !I)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    return pf_flat_search_packed(f, xq, nq, k, D, I, nullptr, stream);
+}
+
+pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, uint32_t *packed, pf_stream stream) {
     if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
     if (nq == 0) return PF_OK;
-    if (!xq || !D || !I) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (!xq || (!packed && (!D || !I))) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (k == 0 || k > K_MAX) return fail(PF_ERR_UNSUPPORTED, "k must be in [1, 1024]");
     if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
@@ -877,7 +886,7 @@ pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, flo
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
-    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I;
+    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I; a.packed = packed;
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = nq <= 32 ? 0 : nq <= 64 ? 1 : 2;

@@ -113,17 +113,16 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ct
 // pf_pack_rows does (coefficient d*j - i <- x[ids[b][j]][i], negated on wrap-around) straight into the registers of the
 // transform -- consecutive lanes read consecutive floats of one row, backwards -- so the coefficient-form plaintext
 // never exists in memory.
-// Coefficient c holds x[row jj][i] with jj = ceil(c / d), i = jj*d - c; jj == N/d is row 0 negated (the wrap-around),
-// jj in [rows, N/d) is empty.  Register k of thread tid is coefficient k*T + tid, so when d divides T (d = 128 with
-// T = 256) i does not depend on k and jj advances by T/d per register: one division per thread.
+// Coefficient c holds x[row jj][i] with jj = ceil(c / d), i = jj*d - c while jj < rows; the top d - 1 coefficients hold
+// row 0 negated (X^-i = -X^(N-i)); the rest is empty.  Register k of thread tid is coefficient k*T + tid, so when d divides
+// T (d = 128 with T = 256) i does not depend on k and jj advances by T/d per register: one division per thread.
 template <class G, class A>
 struct RowsLoader {
     const float *xb; const int64_t *ids; size_t nb; uint32_t d, rows; uint64_t q;
-    __device__ __forceinline__ typename A::V fetch(uint32_t jj, uint32_t i) const {
-        const bool wrap = jj == G::N / d;
-        const uint32_t j = wrap ? 0u : jj;
+    // value of row j, element i (negated for the wrap-around of row 0); `live` false = empty coefficient
+    __device__ __forceinline__ typename A::V value(bool live, bool wrap, uint32_t j, uint32_t i) const {
         float v = 0.f;
-        if (wrap || jj < rows) {
+        if (live) {
             const int64_t id = ids[j];
             if (id >= 0 && (size_t)id < nb) v = rintf(xb[(size_t)id * d + i]);
         }
@@ -132,15 +131,24 @@ struct RowsLoader {
         return A::from_u64(iv >= 0 ? (uint64_t)iv : q - (uint64_t)(-iv));
     }
     __device__ __forceinline__ void operator()(typename A::V (&r)[G::R], int tid) const {
-        if (G::T % d == 0) {                                     // workgroup-uniform
+        if (G::T % d == 0) {                                     // workgroup-uniform; d then divides N as well
+            // jj = ceil(c / d) advances by T/d per register and i = jj*d - c does not depend on the register: one division
+            // per thread.  jj == N/d is row 0 negated (its i equals N - c), jj in [rows, N/d) is empty.
             const uint32_t jj0 = ((uint32_t)tid + d - 1) / d, i = jj0 * d - (uint32_t)tid, step = G::T / d;
 #pragma unroll
-            for (int k = 0; k < G::R; ++k) r[k] = fetch(jj0 + (uint32_t)(G::koff(0, k) / G::T) * step, i);
+            for (int k = 0; k < G::R; ++k) {
+                const uint32_t jj = jj0 + (uint32_t)(G::koff(0, k) / G::T) * step;
+                const bool wrap = jj == G::N / d;
+                r[k] = value(wrap || jj < rows, wrap, wrap ? 0u : jj, i);
+            }
         } else {
+            // any d (the criterion of k_pack_rows): row jj = ceil(c / d) while jj < rows, else the wrap-around of row 0
+            // when N - c < d, else empty
 #pragma unroll
             for (int k = 0; k < G::R; ++k) {
                 const uint32_t c = (uint32_t)(G::koff(0, k) + tid), jj = (c + d - 1) / d;
-                r[k] = fetch(jj, jj * d - c);
+                const bool row = jj < rows, wrap = !row && (uint32_t)G::N - c < d;
+                r[k] = value(row || wrap, wrap, row ? jj : 0u, row ? jj * d - c : (uint32_t)G::N - c);
             }
         }
     }

@@ -21,7 +21,8 @@ def shard_range(n, rank, world):
 
 
 def pack_topk(D, I):
-    """(D [nq,k] float32, I [nq,k] int64) -> one int32 buffer [nq,k,3]: id low word, id high word, distance bits."""
+    """(D [nq,k] float32, I [nq,k] int64) -> one int32 buffer [nq,k,3]: id low word, id high word, distance bits.
+    Host-side definition of the record; on the GPU path the selection kernel writes it directly (FlatL2.search_packed)."""
     nq, k = D.shape
     if I.shape != (nq, k) or D.dtype != torch.float32 or I.dtype != torch.int64:
         raise ValueError("pack_topk: need D [nq,k] float32 and I [nq,k] int64")
@@ -48,6 +49,23 @@ def gather_topk(D, I, group=None, out=None):
     return Dg, Ig, out
 
 
+def search_and_gather(flat, xq_local, k, gathered, group=None):
+    """The multi-GPU step of the pre-filter with no packing pass: this rank's selection kernel writes its block
+    [nq_local, k, 3] IN PLACE at its offset of `gathered` [world * nq_local, k, 3] (int32, preallocated), then ONE
+    all_gather_into_tensor completes every rank's copy (in place on RCCL; other backends get a private send buffer).
+    Returns `gathered`; unpack_topk(gathered) gives (D, I) of all world * nq_local queries in rank order."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nq = xq_local.shape[0]
+    if gathered.shape != (world * nq, k, 3) or gathered.dtype != torch.int32 or not gathered.is_contiguous():
+        raise ValueError("search_and_gather: gathered must be a contiguous int32 [world * nq_local, k, 3]")
+    block = gathered[rank * nq:(rank + 1) * nq]
+    flat.search_packed(xq_local, k, out=block)
+    send = block if dist.get_backend(group) == "nccl" else block.clone()
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    return gathered
+
+
 class ShardedPrefilter:
     """Query-sharded IndexFlatL2 pre-filter: the base matrix is replicated on every rank's GPU; rank r searches
     queries shard_range(nq, r, world) and all ranks end up with the full (D, I)."""
@@ -62,6 +80,6 @@ class ShardedPrefilter:
         if nq % world:
             raise ValueError("ShardedPrefilter.search: nq must be a multiple of the world size (pad the batch)")
         lo, hi = shard_range(nq, rank, world)
-        D, I = self.flat.search(xq_all[lo:hi].contiguous(), k)
-        Dg, Ig, _ = gather_topk(D, I, self.group)
-        return Dg, Ig
+        gathered = torch.empty((nq, k, 3), dtype=torch.int32, device=xq_all.device)
+        search_and_gather(self.flat, xq_all[lo:hi].contiguous(), k, gathered, self.group)
+        return unpack_topk(gathered)

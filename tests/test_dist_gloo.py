@@ -31,8 +31,10 @@ def test_pack_roundtrip_bits():
     assert torch.equal(D.view(torch.int32), D2.view(torch.int32)) and torch.equal(I, I2)
 
 
-class _FakeFlat:
-    """Stands in for prefhetch_amd.FlatL2 on CPU: exact brute force in float64 (test-local, not a product path)."""
+class _CpuIndex:
+    """CPU stand-in with FlatL2's interface (this container has no GPU): exact brute force in float64.  Test-local; the
+    real index under the same collective is exercised on the GPU box by tests/test_gpu_multi.py, which runs bench.py's
+    own control flow with two ranks."""
 
     def __init__(self, xb):
         self.xb = xb
@@ -42,6 +44,11 @@ class _FakeFlat:
         key = torch.argsort(d, dim=1, stable=True)[:, :k]
         return torch.gather(d, 1, key).float(), key
 
+    def search_packed(self, xq, k, out=None):
+        D, I = self.search(xq, k)
+        out.copy_(pfd.pack_topk(D, I))
+        return out
+
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,14 +57,19 @@ def _worker(rank, world, port, out_dir):
         g = torch.Generator().manual_seed(7)
         xb = torch.randint(0, 256, (500, 16), generator=g).float()
         xq = torch.randint(0, 256, (8, 16), generator=g).float()
-        eng = pfd.ShardedPrefilter(_FakeFlat(xb))
+        eng = pfd.ShardedPrefilter(_CpuIndex(xb))
         D, I = eng.search(xq, 5)
-        Dref, Iref = _FakeFlat(xb).search(xq, 5)
+        Dref, Iref = _CpuIndex(xb).search(xq, 5)
         ok = torch.equal(I, Iref) and torch.equal(D, Dref)
         # gather_topk keeps rank order and needs exactly one collective buffer
         lo, hi = pfd.shard_range(8, rank, world)
         Dg, Ig, buf = pfd.gather_topk(Dref[lo:hi], Iref[lo:hi])
         ok = ok and torch.equal(Ig, Iref) and buf.shape == (world * (hi - lo), 5, 3)
+        # the in-place form bench.py uses: the rank's block is written into the gathered buffer, one collective
+        gathered = torch.zeros((8, 5, 3), dtype=torch.int32)
+        pfd.search_and_gather(_CpuIndex(xb), xq[lo:hi].contiguous(), 5, gathered)
+        D2, I2 = pfd.unpack_topk(gathered)
+        ok = ok and torch.equal(I2, Iref) and torch.equal(D2, Dref)
         np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([int(ok)]))
     finally:
         dist.destroy_process_group()

@@ -205,15 +205,19 @@ def test_pack_rows_matches_the_definition(N, qs, rows):
         ctx.pack_rows(flat, torch.zeros((1, N // d + 1), dtype=torch.int64, device=dev))
 
 
-@pytest.mark.parametrize("N,qs,rows,force", [(8192, oracle.BFV_DEFAULT[8192][:4], 64, 0), (1024, oracle.BFV_DEFAULT[1024], 8, 0),
-                                             (4096, oracle.BFV_DEFAULT[4096][:2], 17, 1), (8192, oracle.BFV_DEFAULT[8192][:4], 64, 2)])
-def test_pack_rows_ntt_equals_pack_then_transform(N, qs, rows, force):
+@pytest.mark.parametrize("N,qs,rows,force,d", [(8192, oracle.BFV_DEFAULT[8192][:4], 64, 0, 128), (1024, oracle.BFV_DEFAULT[1024], 8, 0, 128),
+                                               (4096, oracle.BFV_DEFAULT[4096][:2], 17, 1, 128), (8192, oracle.BFV_DEFAULT[8192][:4], 64, 2, 128),
+                                               # row lengths that divide neither the workgroup size nor N: the wrap-around of row 0
+                                               # covers coefficients N-d+1 .. N-1 whatever N mod d is
+                                               (8192, oracle.BFV_DEFAULT[8192][:4], 81, 0, 100), (8192, oracle.BFV_DEFAULT[8192][:4], 85, 0, 96),
+                                               (1024, oracle.BFV_DEFAULT[1024], 10, 0, 100), (4096, oracle.BFV_DEFAULT[4096][:2], 40, 1, 100)])
+def test_pack_rows_ntt_equals_pack_then_transform(N, qs, rows, force, d):
     """pf_pack_rows_ntt (packing fused into the forward transform) against pack_rows -> ntt_forward and against the
     oracle, bit for bit, on every arithmetic back-end."""
     import prefhetch_amd as pf
     dev = _dev()
     rng = np.random.default_rng(N * 3 + rows)
-    nb, d, n_polys = 2000, 128, 7
+    nb, n_polys = 2000, 7
     base = rng.integers(0, 256, (nb, d)).astype(np.float32)
     base[5] = -base[5]
     ids = rng.integers(0, nb, (n_polys, rows)).astype(np.int64)
