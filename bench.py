@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the two stages on separate HIP streams (matrix pipe vs FP64 VALU); per-stage times then overlap")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: all host cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: every core this process may use: affinity mask cut by the cgroup CPU quota)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 through the C-ABI device group (pf_multi_*) in ONE process instead of one process per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the figures outside the timed region (variants, encrypted round, PCIe)")
@@ -104,6 +104,26 @@ def make_queries(rank, B):
     return rng.integers(0, 256, (B, DIM), dtype=np.uint8).astype(np.float32)
 
 
+def usable_cores():
+    """host cores THIS process may run on: the affinity mask, cut by the cgroup CPU quota (the GPU box shows 256 hardware
+    threads and a cpu.max of 16 cores per leased GPU; more threads than the quota only get throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // per))
+        except Exception:
+            pass
+    return (min(n, quota) if quota else n), n, quota
+
+
 def cpu_baseline(threads, ct, pt, xb, xq):
     """The oracle (CPU restatement of the SEAL/faiss algorithms; the reference itself cannot be built here)
     timed on the host cores on a bounded sample of the same workload (a slice of the buffers the GPU ran on):
@@ -120,6 +140,13 @@ def cpu_baseline(threads, ct, pt, xb, xq):
         reps.append(time.perf_counter() - t0)
     t_ct = sorted(reps)[2] / n_ct
     # pre-filter as faiss runs it for nq >= 20: blocked |x|^2 + |y|^2 - 2 x.y with BLAS sgemm + per-query reservoir
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=threads, user_api="blas")
+        blas_threads = max((p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"), default=None)
+    except Exception:
+        limiter = None
     oracle.flat_l2_search_blas(xb[:65536], xq, TOPK, threads=threads)
     reps = []
     for _ in range(3):
@@ -127,18 +154,15 @@ def cpu_baseline(threads, ct, pt, xb, xq):
         oracle.flat_l2_search_blas(xb, xq, TOPK, threads=threads)
         reps.append(time.perf_counter() - t0)
     t_q = sorted(reps)[1] / n_q
-    blas_threads = None
-    try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max((p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"), default=None)
-    except Exception:
-        pass
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {
         "value": 1.0 / (t_ct + t_q), "unit": "encrypted queries/s", "cores": threads, "kind": "port",
         "sample": f"{n_ct} ct x pt (N=8192, 4 limbs, median of 5) + {n_q} flat-L2 queries vs {xb.shape[0]} x 128 (k=200, median of 3; "
-                  f"BLAS sgemm blocks + reservoir as faiss does for nq >= 20), OpenMP {threads} threads (all host cores), "
-                  f"OpenBLAS {blas_threads} threads, same host buffers as the GPU run; restated CPU baseline (SEAL/faiss sources unavailable offline)",
-        "host_cores": os.cpu_count(), "blas_threads": blas_threads,
+                  f"BLAS sgemm blocks + reservoir as faiss does for nq >= 20), OpenMP {threads} threads, OpenBLAS {blas_threads} threads "
+                  f"(= every core this process may use: {usable_cores()[1]} in the affinity mask, cgroup CPU quota {usable_cores()[2]}), "
+                  f"same host buffers as the GPU run; restated CPU baseline (SEAL/faiss sources unavailable offline)",
+        "host_cores": os.cpu_count(), "cgroup_cpu_quota": usable_cores()[2], "blas_threads": blas_threads,
         "ctpt_only_qps": 1.0 / t_ct, "prefilter_only_qps": 1.0 / t_q,
     }
 
@@ -427,7 +451,7 @@ def main():
                 pcie["queries_per_s_if_inputs_and_outputs_crossed_pcie"] = B / ((ms_per_step + pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
             res["pcie_note"] = pcie
         if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or (os.cpu_count() or 1)
+            threads = args.cpu_threads or usable_cores()[0]
             res["cpu_baseline"] = cpu_baseline(threads, h_ct, h_pt, h_xb, h_xq)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
