@@ -51,6 +51,14 @@
 #define PF_SCHED_FENCE() ((void)0)
 #endif
 
+// phase stamps of the diagnostic build (tools/ntt_phase_stamps.hip); nothing in the product
+#ifndef PF_STAMP
+#define PF_STAMP(id) ((void)0)
+#endif
+#ifndef PF_STAMP_X
+#define PF_STAMP_X(step) ((void)0)       // inside an exchange round: 0 entered, 1 first barrier passed, 2 written, 3 second barrier passed, 4 read
+#endif
+
 namespace pf {
 
 struct TwU64 { uint64_t w, wq; };      // twiddle and floor(w*2^64/q)  (SEAL MultiplyUIntModOperand)
@@ -90,6 +98,83 @@ PF_HD uint64_t mulhi64_under(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     return (uint64_t)a1 * b1 + (uint32_t)(((uint64_t)a1 * b0) >> 32) + (uint32_t)(((uint64_t)a0 * b1) >> 32);
 }
+
+// y*w - c*q (mod 2^64), the tail of a Shoup product, as multiply-add chains.  hipcc builds the two 64-bit products
+// separately (2 x {v_mad_u64_u32, 2 v_mul_lo_u32, v_add3_u32}) and subtracts with a carry chain (2 more, plus wait states
+// on the carry): 10 instructions and a nop.  Here the subtraction is an addition of c*(2^64 - q) and every partial
+// product is accumulated by the multiplier itself:
+//     t = y0*w1 + y1*w0 + c0*n1 + c1*n0      4 v_mad_u64_u32; only the low word of t matters
+//     u = y0*w0 + c0*n0                       2 v_mad_u64_u32
+//     result = u + (t << 32)                  1 v_add_u32 on the high word
+// 7 instructions, no carry chain.  NB products go into ONE asm statement, their chains interleaved (hipcc pads every asm
+// statement with a wait state and cannot see inside to schedule).  No instruction here reads a scalar register written by
+// a vector instruction (the carry-out pair `cy` is write-only), so the block needs no wait states of its own.
+// UTW: the twiddles are workgroup-uniform and sit in scalar registers (one scalar operand per instruction either way);
+// nq = 2^64 - q is uniform.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_MS_T0(i) "v_mad_u64_u32 %[t" #i "], %[cy], %[y" #i "0], %[w" #i "1], 0\n\t"
+#define PF_MS_T1(i) "v_mad_u64_u32 %[t" #i "], %[cy], %[y" #i "1], %[w" #i "0], %[t" #i "]\n\t"
+#define PF_MS_T2(i) "v_mad_u64_u32 %[t" #i "], %[cy], %[c" #i "0], %[n1], %[t" #i "]\n\t"
+#define PF_MS_T3(i) "v_mad_u64_u32 %[t" #i "], %[cy], %[c" #i "1], %[n0], %[t" #i "]\n\t"
+#define PF_MS_U0(i) "v_mad_u64_u32 %[u" #i "], %[cy], %[y" #i "0], %[w" #i "0], 0\n\t"
+#define PF_MS_U1(i) "v_mad_u64_u32 %[u" #i "], %[cy], %[c" #i "0], %[n0], %[u" #i "]\n\t"
+#define PF_MS_ALL(OP) OP(0) OP(1) OP(2) OP(3)
+// order: both halves of y are dead once T1 has issued, so u is written OVER y (the tied operand u_i is the pair whose halves
+// the 32-bit operands y_i0 / y_i1 name: same registers, and U0 reads y_i0 in the instruction that overwrites it)
+#define PF_MS_BODY PF_MS_ALL(PF_MS_T0) PF_MS_ALL(PF_MS_T1) PF_MS_ALL(PF_MS_U0) PF_MS_ALL(PF_MS_T2) PF_MS_ALL(PF_MS_U1) PF_MS_ALL(PF_MS_T3)
+#define PF_MS_OUT(i) [t##i] "=&v"(t[i]), [u##i] "+v"(y[i])
+#define PF_MS_IN(i, WC) [y##i##0] "v"((uint32_t)y[i]), [y##i##1] "v"((uint32_t)(y[i] >> 32)), [w##i##0] WC((uint32_t)w[i]), \
+                        [w##i##1] WC((uint32_t)(w[i] >> 32)), [c##i##0] "v"((uint32_t)c[i]), [c##i##1] "v"((uint32_t)(c[i] >> 32))
+template <bool UTW>
+PF_HD void mulsub4_lo64(uint64_t (&y)[4], const uint64_t (&w)[4], const uint64_t (&c)[4], uint64_t nq) {
+    uint64_t t[4], cy;
+    const uint32_t n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+    if constexpr (UTW)
+        asm(PF_MS_BODY : PF_MS_OUT(0), PF_MS_OUT(1), PF_MS_OUT(2), PF_MS_OUT(3), [cy] "=&s"(cy)
+            : PF_MS_IN(0, "s"), PF_MS_IN(1, "s"), PF_MS_IN(2, "s"), PF_MS_IN(3, "s"), [n0] "s"(n0), [n1] "s"(n1));
+    else
+        asm(PF_MS_BODY : PF_MS_OUT(0), PF_MS_OUT(1), PF_MS_OUT(2), PF_MS_OUT(3), [cy] "=&s"(cy)
+            : PF_MS_IN(0, "v"), PF_MS_IN(1, "v"), PF_MS_IN(2, "v"), PF_MS_IN(3, "v"), [n0] "s"(n0), [n1] "s"(n1));
+    // y now holds u.  The sum stays a 32-bit add on the high word (left to itself hipcc builds the pair {0, t} with two
+    // moves and adds 64 bits) ...
+    uint32_t h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (uint32_t)(y[i] >> 32) + (uint32_t)t[i];
+    asm("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = ((uint64_t)h[i] << 32) | (uint32_t)y[i];
+    // ... and the pair stays a pair (or hipcc splits every later 64-bit add of it into two adds of zero-padded halves)
+    asm("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+
+// d[i] = K - m[i] (64 bits, K uniform) for four values at once.  hipcc subtracts through VCC (v_sub_co_u32 / v_subb_co_u32
+// back to back per value) and has to pad every pair with a wait state: a vector instruction may read a carry two states
+// after it was written.  Here the four low halves go first, each with its own carry pair, then the four high halves: three
+// instructions between every write and its read, no padding.  (The high word of K sits in a vector register: the carry
+// pair is the one scalar operand a VOP3 instruction may read.)
+#define PF_SB_LO(i) "v_sub_co_u32 %[l" #i "], %[c" #i "], %[klo], %[m" #i "l]\n\t"
+#define PF_SB_HI(i) "v_subb_co_u32 %[h" #i "], %[c" #i "], %[khi], %[m" #i "h], %[c" #i "]\n\t"
+#define PF_SB_OUT(i) [l##i] "=&v"(lo[i]), [h##i] "=&v"(hi[i]), [c##i] "=&s"(cy[i])
+#define PF_SB_IN(i) [m##i##l] "v"((uint32_t)m[i]), [m##i##h] "v"((uint32_t)(m[i] >> 32))
+PF_HD void sub_from_const4(uint64_t K, const uint64_t (&m)[4], uint64_t (&d)[4]) {
+    uint32_t lo[4], hi[4];
+    uint64_t cy[4];
+    asm(PF_MS_ALL(PF_SB_LO) PF_MS_ALL(PF_SB_HI)
+        : PF_SB_OUT(0), PF_SB_OUT(1), PF_SB_OUT(2), PF_SB_OUT(3)
+        : PF_SB_IN(0), PF_SB_IN(1), PF_SB_IN(2), PF_SB_IN(3), [klo] "s"((uint32_t)K), [khi] "v"((uint32_t)(K >> 32)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = ((uint64_t)hi[i] << 32) | lo[i];
+    asm("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));          // keeps the pairs whole (see mulsub4_lo64)
+}
+#else
+template <bool UTW>
+PF_HD void mulsub4_lo64(uint64_t (&y)[4], const uint64_t (&w)[4], const uint64_t (&c)[4], uint64_t nq) {
+    for (int i = 0; i < 4; ++i) y[i] = y[i] * w[i] + c[i] * nq;
+}
+PF_HD void sub_from_const4(uint64_t K, const uint64_t (&m)[4], uint64_t (&d)[4]) {
+    for (int i = 0; i < 4; ++i) d[i] = K - m[i];
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Geometry
@@ -177,7 +262,7 @@ struct ArithF64 {
     static constexpr bool WQ0_TABLE = true;        // table entries N .. N+R-1 hold fl(w/q) of entries 0 .. R-1
     PF_HD TwR resolve(Tw t) const { return TwR{t.w, t.w * qinv}; }
     static PF_HD TwR with_quotient(Tw t, double wq) { return TwR{t.w, wq}; }
-    template <int NB>
+    template <int NB, bool UTW = false>
     PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {     // y[i] <- y[i]*t[i] (mod q), |.| < q
         double h[NB], l[NB], c[NB];
 #pragma unroll
@@ -230,6 +315,14 @@ struct ArithF64 {
     }
     PF_HD void fwd_combine(V &x, V &y, V m) const { y = x - m; x = x + m; }
     template <int J> PF_HD void inv_split(V &x, V y, V &d) const { d = x - y; x = x + y; }
+    template <int NB> PF_HD void fwd_combine_n(V (&x)[NB], V (&y)[NB], const V (&m)[NB]) const {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fwd_combine(x[i], y[i], m[i]);
+    }
+    template <int J, int NB> PF_HD void inv_split_n(V (&x)[NB], const V (&y)[NB], V (&d)[NB]) const {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) inv_split<J>(x[i], y[i], d[i]);
+    }
     template <int NB> PF_HD void pass_reduce_n(V (&v)[NB]) const { recentre_n<NB>(v); }
     template <int NB> PF_HD void for_dyadic_n(V (&)[NB]) const {}
     PF_HD V add(V a, V b) const { return a + b; }
@@ -263,13 +356,16 @@ inline unsigned long long pf_range_violations = 0;          // host simulator on
 #define PF_RANGE_ASSERT(c) do { } while (0)
 #endif
 
+#ifndef PF_U64_HALF_EXCHANGE
+#define PF_U64_HALF_EXCHANGE 0
+#endif
 template <bool LAZY>
 struct ArithU64T {
     using V = uint64_t;
     using Tw = TwU64;
     using TwR = TwU64;
     static constexpr bool PREFETCH_TW = false;     // 16-byte twiddles: fetched after the exchange (register budget)
-    static constexpr bool HALF_EXCHANGE_OK = false; // 64-bit integer butterflies need the 256-VGPR budget: two workgroups per CU
+    static constexpr bool HALF_EXCHANGE_OK = PF_U64_HALF_EXCHANGE; // 64-bit integer butterflies: 0 = 256-VGPR budget (whole exchange), 1 = half-buffer exchange
     uint64_t q, two_q, ratio0, ratio1;               // ratio = floor(2^128/q)
 
     static PF_HD V from_u64(uint64_t x) { return x; }
@@ -279,14 +375,60 @@ struct ArithU64T {
     static PF_HD TwR with_quotient(Tw t, double) { return t; }
     PF_HD V guard(V v) const { return v >= two_q ? v - two_q : v; }
     PF_HD V shoup_one(V v) const { return v - mulhi64(v, ratio1) * q; }                // any v < 2^64 -> [0, 2q)
-    template <int NB>
+    // UTW: the twiddles of this call are workgroup-uniform (first pass)
+    template <int NB, bool UTW = false>
     PF_HD void mul_tw_n(V (&y)[NB], const TwR (&t)[NB]) const {
         uint64_t hi[NB];
+        const uint64_t nq = 0 - q;
 #pragma unroll
         for (int i = 0; i < NB; ++i) hi[i] = LAZY ? mulhi64_under(y[i], t[i].wq) : mulhi64(y[i], t[i].wq);
         PF_SCHED_FENCE();
+        static_assert(NB % 4 == 0, "products go in fours");
 #pragma unroll
-        for (int i = 0; i < NB; ++i) y[i] = y[i] * t[i].w - hi[i] * q;                 // [0,2q), LAZY: [0,4q)
+        for (int i = 0; i < NB; i += 4) {                                               // y*w - hi*q: [0,2q), LAZY: [0,4q)
+            uint64_t yy[4] = {y[i], y[i + 1], y[i + 2], y[i + 3]};
+            const uint64_t ww[4] = {t[i].w, t[i + 1].w, t[i + 2].w, t[i + 3].w}, cc[4] = {hi[i], hi[i + 1], hi[i + 2], hi[i + 3]};
+            mulsub4_lo64<UTW>(yy, ww, cc, nq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[i + e] = yy[e];
+        }
+    }
+    // batched butterfly halves (NB a multiple of four): the lazy family subtracts through sub_from_const4
+    template <int NB> PF_HD void fwd_combine_n(V (&x)[NB], V (&y)[NB], const V (&m)[NB]) const {
+        if constexpr (LAZY && NB % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < NB; i += 4) {
+                const V mm[4] = {m[i], m[i + 1], m[i + 2], m[i + 3]};
+                V d[4];
+                sub_from_const4(two_q << 1, mm, d);                                     // 4q - m
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    PF_RANGE_ASSERT(mm[e] < (two_q << 1) && x[i + e] <= ~0ull - (two_q << 1));
+                    y[i + e] = x[i + e] + d[e]; x[i + e] = x[i + e] + mm[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fwd_combine(x[i], y[i], m[i]);
+        }
+    }
+    template <int J, int NB> PF_HD void inv_split_n(V (&x)[NB], const V (&y)[NB], V (&d)[NB]) const {
+        if constexpr (LAZY && NB % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < NB; i += 4) {
+                const V yy[4] = {y[i], y[i + 1], y[i + 2], y[i + 3]};
+                V t[4];
+                sub_from_const4(two_q << (J + 1), yy, t);                               // B - y
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    PF_RANGE_ASSERT(x[i + e] < (two_q << (J + 1)) && yy[e] < (two_q << (J + 1)) && (two_q << (J + 1)) <= (1ull << 63));
+                    d[i + e] = x[i + e] + t[e]; x[i + e] = x[i + e] + yy[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) inv_split<J>(x[i], y[i], d[i]);
+        }
     }
     PF_HD void fwd_combine(V &x, V &y, V m) const {
         if constexpr (LAZY) {
@@ -427,11 +569,18 @@ PF_HD void fwd_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, P
             ys[i] = r[k0 | (1 << KB)];
             ts[i] = T.get(ar, KB, b >> KB);
         }
-        ar.template mul_tw_n<NBATCH>(ys, ts);
+        ar.template mul_tw_n<NBATCH, PASS == 0>(ys, ts);
+        V xs[NBATCH], yo[NBATCH];
 #pragma unroll
         for (int i = 0; i < NBATCH; ++i) {
             const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
-            ar.fwd_combine(r[k0], r[k0 | (1 << KB)], ys[i]);
+            xs[i] = r[k0];
+        }
+        ar.template fwd_combine_n<NBATCH>(xs, yo, ys);
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            r[k0] = xs[i]; r[k0 | (1 << KB)] = yo[i];
         }
     }
     if constexpr (KB > 0) fwd_stage<G, A, PASS, KB - 1>(r, ar, T);
@@ -452,13 +601,20 @@ PF_HD void inv_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, P
             V ds[NBATCH];
             TwR ts[NBATCH];
             PF_SCHED_FENCE();
+            V xs[NBATCH], yi[NBATCH];
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
-                ar.template inv_split<KB>(r[k0], r[k0 | (1 << KB)], ds[i]);
+                xs[i] = r[k0]; yi[i] = r[k0 | (1 << KB)];
                 ts[i] = T.get(ar, KB, b >> KB);
             }
-            ar.template mul_tw_n<NBATCH>(ds, ts);
+            ar.template inv_split_n<KB, NBATCH>(xs, yi, ds);
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) {
+                const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+                r[k0] = xs[i];
+            }
+            ar.template mul_tw_n<NBATCH, PASS == 0>(ds, ts);
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
@@ -489,7 +645,7 @@ PF_HD void inv_pass(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PA
                 ar.template inv_split<G::nl(0) - 1>(vs[2 * i], r[j + G::R / 2], vs[2 * i + 1]);
                 ts[2 * i] = tn; ts[2 * i + 1] = t;
             }
-            ar.template mul_tw_n<NBATCH>(vs, ts);
+            ar.template mul_tw_n<NBATCH, true>(vs, ts);
 #pragma unroll
             for (int i = 0; i < NBATCH / 2; ++i) { r[bb + i] = vs[2 * i]; r[bb + i + G::R / 2] = vs[2 * i + 1]; }
         }
@@ -603,7 +759,9 @@ template <class G, class A, int WR, int RD, class Sync>
 PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAddr<G, (WR < RD ? WR : RD), WR, G::N / 2 - 1> &aw,
                       const XchgAddr<G, (WR < RD ? WR : RD), RD, G::N / 2 - 1> &ard, int sel, Sync &&sync) {
     constexpr int H = G::R / 2;
+    PF_STAMP_X(0);
     sync();
+    PF_STAMP_X(1);
     if (sel) {
         PF_BRANCH_TAG("upper half: write");
 #pragma unroll
@@ -615,7 +773,9 @@ PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAd
         for (int j = 0; j < H; ++j) *aw.at(lds, j) = r[j];
         PF_BRANCH_TAG("lower half: written");
     }
+    PF_STAMP_X(2);
     sync();
+    PF_STAMP_X(3);
     if (sel) {
         PF_BRANCH_TAG("upper half: read");
 #pragma unroll
@@ -627,6 +787,7 @@ PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAd
         for (int j = 0; j < H; ++j) r[j] = *ard.at(lds, j);
         PF_BRANCH_TAG("lower half: read done");
     }
+    PF_STAMP_X(4);
 }
 
 template <class G, class A, int WR, int RD, class Sync>
@@ -674,8 +835,11 @@ template <class G, class A, bool HEAD_EARLY = false, class Sync>
 PF_HD void fwd_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
                    typename A::V *lds, int tid, Sync &&sync) {
     { PassTw<G, A, 0> t0; t0.template load<true>(tw, tid); fwd_pass<G, A, 0>(r, ar, t0); }
-    if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 1>(r, ar, t); }
-    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 2>(r, ar, t); }
+    PF_STAMP(2);
+    if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1, HEAD_EARLY>(r, t, tw, lds, tid, sync); PF_STAMP(3); fwd_pass<G, A, 1>(r, ar, t); }
+    PF_STAMP(4);
+    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2, HEAD_EARLY>(r, t, tw, lds, tid, sync); PF_STAMP(5); fwd_pass<G, A, 2>(r, ar, t); }
+    PF_STAMP(6);
     if constexpr (G::P >= 4) { PassTw<G, A, 3> t; xchg_and_load<G, A, 2, 3, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, t); }
 }
 
@@ -684,6 +848,7 @@ template <class G, class A, class Sync>
 PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, G::LAST> &tl, const typename A::Tw *__restrict__ itw,
                    typename A::V *lds, int tid, Sync &&sync) {
     inv_pass<G, A, G::LAST>(r, ar, tl, itw);
+    PF_STAMP(9);
     if constexpr (G::P >= 4) {
         PassTw<G, A, 2> t;
         pass_reduce_all<G, A, 3>(r, ar);
@@ -694,13 +859,17 @@ PF_HD void inv_all(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, G::
         PassTw<G, A, 1> t;
         pass_reduce_all<G, A, 2>(r, ar);
         xchg_and_load<G, A, 2, 1>(r, t, itw, lds, tid, sync);
+        PF_STAMP(10);
         inv_pass<G, A, 1>(r, ar, t, itw);
+        PF_STAMP(11);
     }
     if constexpr (G::P >= 2) {
         PassTw<G, A, 0> t;
         pass_reduce_all<G, A, 1>(r, ar);
         xchg_and_load<G, A, 1, 0>(r, t, itw, lds, tid, sync);
+        PF_STAMP(12);
         inv_pass<G, A, 0>(r, ar, t, itw);
+        PF_STAMP(13);
     }
 }
 
@@ -756,6 +925,50 @@ PF_HD void store_last(const uint64_t (&o)[G::R], uint64_t *dst, int tid) {
     }
 }
 
+// Layout LAST -> memory with every store instruction covering whole 64-byte segments.  In layout LAST a lane owns a run of
+// 2^nl consecutive coefficients, so a plain 16-byte store per lane lands at a 64-byte (or wider) lane stride; measured on
+// MI355X (tools/ubench_stride.hip) such stores run at 0.93 TB/s against 3.27 TB/s lane-contiguous (loads do not care:
+// 6.2 against 6.5 TB/s).  Consecutive lanes of a quad own consecutive runs, so the four lanes exchange 16-byte items
+// through a wave-private staging area in LDS (the exchange buffer, idle by now): lane l writes its run at l * 80 bytes (the
+// 80-byte pitch keeps both sides free of bank conflicts), then for store j lane (4g + i) reads item i of lane (4g + j) and
+// writes it behind that lane's run: the quad covers 64 contiguous bytes.  LDS operations of one wave execute in order, so
+// the staging area needs no barrier of its own; `sync` is called once up front, because other waves may still be reading
+// the last exchange out of the buffer.  Host build (one OS thread per lane): plain stores, same bytes.
+template <class G, class V, class Sync>
+PF_HD void store_last_staged(const uint64_t (&o)[G::R], uint64_t *dst, int tid, V *lds, Sync &&sync) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int L = G::LAST, NL = G::nl(L);
+    constexpr int y = G::P >= 2 ? G::YBIT - NL : 0;            // low y lane bits count runs in order (Geo::base)
+    constexpr int PITCH = 80, WAVES = G::T / 64;
+    if constexpr (NL >= 3 && y >= 2 && G::T >= 64 && (size_t)WAVES * 64 * PITCH <= sizeof(V) * (G::N / 2)) {
+        const int lane = tid & 63, b = G::base(L, tid);
+        char *stage = reinterpret_cast<char *>(lds) + (size_t)(tid >> 6) * (64 * PITCH);
+        U64x2 *mine = reinterpret_cast<U64x2 *>(stage + lane * PITCH);
+        const int quad0 = lane & ~3, i = lane & 3;
+        sync();
+#pragma unroll
+        for (int k = 0; k < G::R; k += 8) {                      // one half-run-or-run of 8 coefficients = 4 items
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine[c] = U64x2{o[k + 2 * c], o[k + 2 * c + 1]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const U64x2 v = reinterpret_cast<const U64x2 *>(stage + (quad0 + j) * PITCH)[i];
+                // lane (quad0 + j) keeps its 8 coefficients at koff(L, k) + base(quad0 + j) = ... + b + (j - i) * 2^NL
+                *reinterpret_cast<U64x2 *>(dst + G::koff(L, k) + b + (j - i) * (1 << NL) + 2 * i) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        store_last<G>(o, dst, tid);
+    }
+#else
+    (void)lds; (void)sync;
+    store_last<G>(o, dst, tid);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernel bodies
 // ------------------------------------------------------------------------------------------------
@@ -766,13 +979,17 @@ template <class G, class A, class Sync>
 PF_HD void body_ntt_fwd(const A &ar, const typename A::Tw *__restrict__ tw, const uint64_t *src,
                         uint64_t *dst, typename A::V *lds, int tid, Sync &&sync) {
     typename A::V r[G::R];
+    PF_STAMP(0);
     load_l0<G, A>(r, src, tid);
+    PF_STAMP(1);
     fwd_all<G, A, true>(r, ar, tw, lds, tid, sync);
     canon_all<G, A>(r, ar);
+    PF_STAMP(7);
     uint64_t o[G::R];
 #pragma unroll
     for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
-    store_last<G>(o, dst, tid);
+    store_last_staged<G>(o, dst, tid, lds, sync);
+    PF_STAMP(8);
 }
 
 // forward NTT of an RNS digit under another modulus: dst = NTT_q(src mod q)   (key switching, step 1)
@@ -786,7 +1003,7 @@ PF_HD void body_ntt_fwd_mod(const A &ar, const typename A::Tw *__restrict__ tw, 
     uint64_t o[G::R];
 #pragma unroll
     for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
-    store_last<G>(o, dst, tid);
+    store_last_staged<G>(o, dst, tid, lds, sync);
 }
 
 template <class G, class A, class Sync>
@@ -815,12 +1032,16 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
         dyadic_all<G, A, false>(r, pv, ar);
         if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);
     } else {
+        PF_STAMP(0);
         load_l0<G, A>(r, ct, tid);
+        PF_STAMP(1);
         fwd_all<G, A>(r, ar, tw, lds, tid, sync);
         // the plaintext limb is read in the layout the forward transform ended in: lane-contiguous from HBM
         load_last<G, A>(pv, pt, tid);
+        PF_STAMP(7);
         dyadic_all<G, A, true>(r, pv, ar);
         if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);
+        PF_STAMP(8);
     }
     if constexpr (FLAGS & CTPT_OUT_NTT) {
         uint64_t o[G::R];
@@ -842,6 +1063,7 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
         if constexpr (FLAGS & CTPT_ACCUMULATE) v = ar.canon_sum(ar.add(v, A::from_u64((out + G::koff(0, k))[tid])));
         (out + G::koff(0, k))[tid] = A::to_u64(v);
     }
+    PF_STAMP(14);
 }
 
 // Forward transform of a polynomial that is PRODUCED instead of read: `load(r, tid)` fills register k with coefficient
@@ -856,7 +1078,7 @@ PF_HD void body_ntt_fwd_from(const A &ar, const typename A::Tw *__restrict__ tw,
     uint64_t o[G::R];
 #pragma unroll
     for (int k = 0; k < G::R; ++k) o[k] = A::to_u64(r[k]);
-    store_last<G>(o, dst, tid);
+    store_last_staged<G>(o, dst, tid, lds, sync);
 }
 
 }  // namespace pf
