@@ -217,6 +217,13 @@ class FlatL2:
 
     __del__ = close
 
+    def exact16(self, mode=-1):
+        """16-bit operand path for exactly-representable data (pf_flat_exact16): mode 1 on where the data allows (default),
+        0 fp32 operands always, -1 query.  Returns True when the base passed the on-device check and the path is on."""
+        a = C.c_int()
+        check(lib.pf_flat_exact16(self._h, int(mode), C.byref(a)), "pf_flat_exact16")
+        return bool(a.value)
+
     def reserve(self, nq_max, k_max):
         check(lib.pf_flat_reserve(self._h, nq_max, k_max), "pf_flat_reserve")
 

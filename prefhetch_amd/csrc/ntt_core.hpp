@@ -357,7 +357,7 @@ inline unsigned long long pf_range_violations = 0;          // host simulator on
 #endif
 
 #ifndef PF_U64_HALF_EXCHANGE
-#define PF_U64_HALF_EXCHANGE 0
+#define PF_U64_HALF_EXCHANGE 1      // measured (r02): 2-3 workgroups per CU beat the 256-register budget by 7-15 % at N <= 16384
 #endif
 template <bool LAZY>
 struct ArithU64T {

@@ -61,6 +61,41 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
     out[i] = acc;
 }
 
+// ---- bf16 operands for exactly-representable data --------------------------------------------------------------
+// SIFT-like vectors (the reference's dataset: 8-bit values stored as fp32) are integers of magnitude <= 256: exact in
+// bf16 (8 significant bits), every product x*y is an integer below 2^16 and, with d <= 256, every partial sum of a dot
+// product is an integer of magnitude <= 2^24 -- exactly representable in fp32.  The bf16 matrix instruction
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) therefore returns the same accumulator, bit for bit, as the k-ordered
+// fp32 fmaf chain of the f32 instruction, whatever order it adds in, at 16 times the rate; norms and the final
+// fmaf(-2, acc, |x|^2 + |y|^2) are computed by the same code on both paths.  Eligibility is CHECKED ON THE DEVICE, value by
+// value (integer, |v| <= 256): the base when the index is created (the 16-bit image is dropped if a single value fails), the
+// queries at the start of every search (per 128-query tile; a tile with an inexact value runs the fp32 loop).  Nothing is
+// assumed about the data, and a search needs no host synchronisation to pick its path.
+constexpr float BF16_EXACT_MAX = 256.f;
+constexpr uint32_t BF16_MAX_D = 256;
+__device__ __forceinline__ bool bf16_exact(float v) { return v == rintf(v) && fabsf(v) <= BF16_EXACT_MAX; }
+
+// row norms (fp32 fma chain in index order) + 16-bit image + eligibility; one thread per row
+__global__ void __launch_bounds__(256) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
+                                                   uint16_t *__restrict__ x16, uint32_t *__restrict__ inexact, uint32_t rows_per_flag) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = x + i * d;
+    float acc = 0.f;
+    bool ok = true;
+    for (uint32_t k = 0; k < d; ++k) {
+        const float v = r[k];
+        acc = fmaf(v, v, acc);
+        ok = ok && bf16_exact(v);
+        if (x16) x16[i * d + k] = (uint16_t)(__float_as_uint(v) >> 16);       // exact when ok; unused otherwise
+    }
+    norms[i] = acc;
+    if (!ok && inexact) atomicOr(&inexact[rows_per_flag ? i / rows_per_flag : 0], 1u);
+}
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;      // 16 bytes in registers (HIP's uint4 struct in an array stays in scratch)
+
 // One 128x128 tile of distances per workgroup (256 threads = 4 waves, each wave a 64x64 quadrant as
 // 2x2 MFMA 32x32 tiles).  Rows of the tile are queries, columns are base rows, so that a stored
 // accumulator register covers 32 consecutive floats of one query's slab row.
@@ -73,6 +108,9 @@ struct TileArgs {
     uint64_t *cand;         // [nq][cap] packed keys
     uint32_t cap;
     uint32_t n_qtiles;
+    // exactly-representable data (see "bf16 operands" below): 16-bit images of the queries / the base, and per 128-query
+    // tile a word that is non-zero when some value of the tile is NOT exactly representable (then the fp32 loop runs)
+    const uint16_t *xq16; const uint16_t *xb16; const uint32_t *q_inexact;
 };
 
 // Tile geometry: TM queries x TN base rows per workgroup of 256 threads (4 waves laid out WM x WN); a wave owns
@@ -142,11 +180,17 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
 
 // AGG (the 32- and 64-row geometries): survivors are aggregated per row in LDS before the global append -- with few
 // queries the global counters are hot, and a workgroup there spans 256 columns of every row.
-template <bool FILTER, class GEO, bool FAST, bool AGG = false>   // AGG only matters with FILTER
+// BF16 (batch geometry, d a multiple of 64, base image present): tiles whose queries are exactly representable run the
+// bf16 loop below instead of the fp32 slab loop; the epilogue is shared.
+constexpr int B16_KH = 64;                          // k-depth staged per step (d = 128: two steps)
+constexpr int B16_PITCH = B16_KH * 2 + 16;          // bytes per LDS row: 128 of data + 16 of padding (conflict-free b128 access)
+template <bool FILTER, class GEO, bool FAST, bool AGG = false, bool BF16 = false>   // AGG only matters with FILTER
 __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
-    __shared__ __align__(16) float sAb[2][TK * LDA];   // two k-slabs in flight: one feeds the MFMAs, the next is being filled
-    __shared__ float sBb[2][TK * LDB];
+    constexpr size_t F32_BYTES = sizeof(float) * 2 * TK * (LDA + LDB), B16_BYTES = BF16 ? (size_t)(TM + TN) * B16_PITCH : 0;
+    __shared__ __align__(16) char smem[F32_BYTES > B16_BYTES ? F32_BYTES : B16_BYTES];
+    float (*sAb)[TK * LDA] = reinterpret_cast<float (*)[TK * LDA]>(smem);   // two k-slabs in flight: one feeds the MFMAs, the next is being filled
+    float (*sBb)[TK * LDB] = reinterpret_cast<float (*)[TK * LDB]>(smem + sizeof(float) * 2 * TK * LDA);
     float *const sA = sAb[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
@@ -182,6 +226,61 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     if constexpr (FILTER) {
         if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
     }
+    bool f32_loop = true;
+    if constexpr (BF16) {
+        static_assert(TM == 128 && TN == 128 && GEO::THREADS == 256, "the bf16 loop is written for the batch geometry");
+        if (p.q_inexact[qt] == 0) {                                   // workgroup-uniform
+            f32_loop = false;
+            char *const sA16 = smem, *const sB16 = smem + TM * B16_PITCH;
+            // staging: a row's 128 bytes are covered by 8 lanes x 16 bytes; rows past the end re-read the last valid row
+            // (their products land in accumulator rows / columns the epilogue never emits)
+            const int srow = tid >> 3, sseg = tid & 7;
+            uint32_t oa[4], ob[4];                                    // element offsets from the tile's first row (32 bits: a tile spans < 2^31 elements)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t ra_ = (size_t)(srow + 32 * it) < q_valid ? srow + 32 * it : (uint32_t)q_valid - 1;
+                const uint32_t rb_ = (size_t)(srow + 32 * it) < c_valid ? srow + 32 * it : (uint32_t)c_valid - 1;
+                oa[it] = ra_ * p.d + sseg * 8;
+                ob[it] = rb_ * p.d + sseg * 8;
+            }
+            const uint16_t *const abase = p.xq16 + q0 * (size_t)p.d, *const bbase = p.xb16 + (p.nb_first + c0) * (size_t)p.d;
+            // One k-step of 64 at a time, operands held in registers only between the load and the LDS write: the four
+            // workgroups resident on a CU cover each other's load latency, and the registers go to occupancy instead of a
+            // second operand set (with one, hipcc spilled it -- every load followed by a wait and a scratch store)
+            for (uint32_t k0 = 0; k0 < p.d; k0 += B16_KH) {
+                u32x4 va[4], vb[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    va[it] = *reinterpret_cast<const u32x4 *>(abase + oa[it] + k0);
+                    vb[it] = *reinterpret_cast<const u32x4 *>(bbase + ob[it] + k0);
+                }
+                if (k0) __syncthreads();                              // the previous step's fragments have been read
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    *reinterpret_cast<u32x4 *>(sA16 + (srow + 32 * it) * B16_PITCH + sseg * 16) = va[it];
+                    *reinterpret_cast<u32x4 *>(sB16 + (srow + 32 * it) * B16_PITCH + sseg * 16) = vb[it];
+                }
+                __syncthreads();
+                // lane l feeds row (l & 31), k = 8 * (l >> 5) .. + 7 of every 16-deep step: 16 contiguous bytes of an LDS row
+                const char *fa = sA16 + (wm + (lane & 31)) * B16_PITCH + (lane >> 5) * 16;
+                const char *fb = sB16 + (wn + (lane & 31)) * B16_PITCH + (lane >> 5) * 16;
+#pragma unroll
+                for (int ks = 0; ks < B16_KH / 16; ++ks) {
+                    bf16x8 a[MI], b[NJ];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(fa + 32 * i * B16_PITCH + ks * 32);
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj) b[jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * B16_PITCH + ks * 32);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (f32_loop) {
     float4 ra[GEO::ITA], rb[GEO::ITB];
     slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
     slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
@@ -228,6 +327,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         }
         __syncthreads();
     }
+    }   // f32_loop
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     if constexpr (FILTER) {
         // per-query norm and threshold of this tile's rows, staged in LDS (sA is free now)
@@ -743,6 +843,8 @@ struct pf_flat {
     size_t nb = 0;
     uint32_t d = 0;
     float *xb = nullptr, *bn = nullptr;
+    uint16_t *xb16 = nullptr;     // bf16 image of the base matrix: present only if EVERY value passed the on-device exactness check
+    bool use16 = true;            // pf_flat_exact16: the caller may switch the 16-bit operand path off
     // workspace (grown outside graph capture)
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -757,9 +859,9 @@ constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
 #endif
 constexpr size_t MAX_CHUNK = PF_MAX_CHUNK; // largest streaming chunk (bounds the cost of one overflow rescan)
 
-struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, total; };
+struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_qbad, total; };
 
-WsPlan plan_ws(size_t nb, size_t nq, uint32_t k) {
+WsPlan plan_ws(size_t nb, size_t nq, uint32_t k, uint32_t d) {
     WsPlan w{};
     const size_t nb_pad = (nb + 127) / 128 * 128;
     w.boot = BOOT_ROWS < nb_pad ? BOOT_ROWS : (nb_pad ? nb_pad : 128);
@@ -774,6 +876,8 @@ WsPlan plan_ws(size_t nb, size_t nq, uint32_t k) {
     w.off_state = o; o += up(nq * (size_t)k * 8);
     w.off_cand = o; o += up(nq * w.cap * 8);
     w.off_slab = o; o += up(nq * w.slab_ld * 4);
+    w.off_q16 = o; o += up(nq * (size_t)d * 2);
+    w.off_qbad = o; o += up(((nq + 127) / 128) * 4);
     w.total = o;
     return w;
 }
@@ -805,6 +909,7 @@ pf_status pf_flat_destroy(pf_flat *f) {
     {
         DeviceGuard g(f->device);
         if (f->xb) (void)hipFree(f->xb);
+        if (f->xb16) (void)hipFree(f->xb16);
         if (f->bn) (void)hipFree(f->bn);
         if (f->ws) (void)hipFree(f->ws);
     }
@@ -826,9 +931,24 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     if (e == hipSuccess) e = hipMalloc((void **)&f->bn, (nb ? nb : 1) * 4);
     if (e == hipSuccess && nb) e = hipMemcpy(f->xb, xb, nb * (size_t)d * 4, hipMemcpyDefault);
     if (e == hipSuccess && nb) {
-        hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
+        // row norms; and, where the shape allows the bf16 loop, the 16-bit image with its value-by-value exactness check
+        uint32_t *flag = nullptr;
+        const bool try16 = d % B16_KH == 0 && d <= BF16_MAX_D && getenv("PF_FLAT_NO_BF16") == nullptr;
+        if (try16 && (hipMalloc((void **)&f->xb16, nb * (size_t)d * 2) != hipSuccess || hipMalloc((void **)&flag, 4) != hipSuccess ||
+                      hipMemset(flag, 0, 4) != hipSuccess)) {
+            (void)hipGetLastError();                                  // no room for the image: the fp32 path needs none
+            if (f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }
+            if (flag) { (void)hipFree(flag); flag = nullptr; }
+        }
+        hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, flag, 0u);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (flag) {
+            uint32_t inexact = 1;
+            if (e == hipSuccess) e = hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost);
+            (void)hipFree(flag);
+            if (inexact && f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }     // one inexact value: fp32 operands only
+        }
     }
     if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
     {
@@ -843,6 +963,13 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     return PF_OK;
 }
 
+pf_status pf_flat_exact16(pf_flat *f, int mode, int *active) {
+    if (!f || mode < -1 || mode > 1) return fail(PF_ERR_INVALID_ARG, "pf_flat_exact16: index, and mode -1 (query), 0 (off) or 1 (on where exact)");
+    if (mode >= 0) f->use16 = mode == 1;
+    if (active) *active = f->xb16 && f->use16 ? 1 : 0;
+    return PF_OK;
+}
+
 pf_status pf_flat_info(const pf_flat *f, size_t *nb, uint32_t *d) {
     if (!f) return fail(PF_ERR_INVALID_ARG, "null index");
     if (nb) *nb = f->nb;
@@ -853,7 +980,7 @@ pf_status pf_flat_info(const pf_flat *f, size_t *nb, uint32_t *d) {
 pf_status pf_flat_reserve(pf_flat *f, size_t nq_max, uint32_t k_max) {
     if (!f || nq_max == 0 || k_max == 0) return fail(PF_ERR_INVALID_ARG, "bad argument");
     PF_GUARD(f->device);
-    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max).total);
+    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max, f->d).total);
 }
 
 pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream) {
@@ -869,7 +996,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
     hipStream_t s = as_stream(stream);
-    const WsPlan w = plan_ws(f->nb, nq, k);
+    const WsPlan w = plan_ws(f->nb, nq, k, f->d);
     pf_status st = ensure_ws(f, w.total);
     if (st != PF_OK) return st;
     char *base = static_cast<char *>(f->ws);
@@ -880,8 +1007,14 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     uint64_t *state = reinterpret_cast<uint64_t *>(base + w.off_state);
     uint64_t *cand = reinterpret_cast<uint64_t *>(base + w.off_cand);
     float *slab = reinterpret_cast<float *>(base + w.off_slab);
-    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
+    const bool b16 = f->xb16 && f->use16 && nq > 64;                 // batch geometry only
+    uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
+    uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
+    if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
+    hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr,
+                       b16 ? qbad : nullptr, 128u);
     TileArgs t{};
+    t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};
@@ -906,8 +1039,12 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             case 1: if (agg) PF_TILE(true, GeoSmall32, true); else PF_TILE(true, GeoSmall32, false); break;
             case 2: PF_TILE(false, GeoSmall64, false); break;
             case 3: PF_TILE(true, GeoSmall64, true); break;
-            case 4: PF_TILE(false, GeoBatch, false); break;
-            default: PF_TILE(true, GeoBatch, false); break;
+            case 4: if (b16) hipLaunchKernelGGL((k_l2_tile<false, GeoBatch, true, false, true>), grid, dim3(256), 0, s, t);
+                    else PF_TILE(false, GeoBatch, false);
+                    break;
+            default: if (b16) hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, true, false, true>), grid, dim3(256), 0, s, t);
+                     else PF_TILE(true, GeoBatch, false);
+                     break;
         }
 #undef PF_TILE
     };

@@ -302,3 +302,72 @@ def test_step_captured_in_a_hip_graph(pf, capsys):
     eager, replay = ms(lambda: big.search(q1, 200)), ms(g1.replay)
     with capsys.disabled():
         print(f"\n[hipGraph] single-query search over 1M x 128: eager {eager:.3f} ms, graph replay {replay:.3f} ms")
+
+
+def _search_both(pf, xb, xq, k):
+    """(D, I) with the 16-bit operand path on and off, plus whether the index took the path"""
+    dev = _dev()
+    f = pf.FlatL2(xb, dev)
+    q = torch.from_numpy(xq).to(dev)
+    active = f.exact16()
+    D1, I1 = f.search(q, k)
+    f.exact16(0)
+    assert not f.exact16()
+    D0, I0 = f.search(q, k)
+    return active, (D1.cpu().numpy(), I1.cpu().numpy()), (D0.cpu().numpy(), I0.cpu().numpy())
+
+
+@pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (192, 70, 100), (256, 128, 64)])
+def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
+    """exactly-representable data (integers, |v| <= 256): the bf16-operand tiles must return the fp32 loop's (D, I) and the
+    oracle's, bit for bit -- including the extreme values +-256 and heavy ties"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(d + nq)
+    xb = rng.integers(-256, 257, (40000, d)).astype(np.float32)
+    xq = rng.integers(-256, 257, (nq, d)).astype(np.float32)
+    xb[:50] = 256.0; xq[0] = -256.0; xq[1] = 256.0                 # largest products, largest sums
+    xb[100:400] = xb[100]                                            # a plateau of ties
+    active, got16, got32 = _search_both(pf, xb, xq, k)
+    assert active
+    assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
+    # against the oracle on the 8-bit range.  d <= 128: |x|^2 + |y|^2 stays below 2^24, so the fp32 formula
+    # |x|^2 + |y|^2 - 2 x.y is exact and distances match bit for bit; wider rows round that sum once (both paths alike)
+    xb, xq = np.abs(xb).clip(0, 255), np.abs(xq).clip(0, 255)
+    active, got16, got32 = _search_both(pf, xb, xq, k)
+    Dr, Ir = oracle.flat_l2_search(xb, xq, k)
+    assert active and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all() and (got16[1] == got32[1]).all()
+    if d <= 128:
+        assert (got16[1] == Ir).all() and (got16[0] == Dr).all()
+    else:
+        assert np.allclose(got16[0], Dr, rtol=RTOL, atol=0) and (np.sort(got16[1], axis=1) == np.sort(Ir, axis=1)).mean() > 0.99
+
+
+def test_exact16_path_refuses_inexact_data():
+    """one value outside the exactly-representable set switches the path off: a fraction, a large integer, a huge d"""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(8)
+    base = rng.integers(0, 256, (5000, 128)).astype(np.float32)
+    for bad in (0.5, 257.0, -300.0, 1e6):
+        xb = base.copy()
+        xb[1234, 77] = bad
+        assert not pf.FlatL2(xb, dev).exact16()
+    assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
+    assert not pf.FlatL2(rng.integers(0, 256, (500, 100)).astype(np.float32), dev).exact16()      # d not a multiple of 64
+    assert pf.FlatL2(base, dev).exact16()
+
+
+def test_exact16_query_tile_falls_back_per_tile():
+    """the base is exact, ONE query is not: its 128-query tile runs the fp32 loop, the others the bf16 loop; every result
+    still equals the fp32 path's"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(9)
+    xb = rng.integers(0, 256, (30000, 128)).astype(np.float32)
+    xq = rng.integers(0, 256, (384, 128)).astype(np.float32)
+    xq[200, 5] = 0.25                                                # tile 1 of 3
+    xq[383, 0] = 1000.0                                              # tile 2: large but integer -- outside the bound
+    active, got16, got32 = _search_both(pf, xb, xq, 50)
+    assert active
+    assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
+    Dr, Ir = oracle.flat_l2_search(xb, xq[:128], 50)
+    assert (got16[1][:128] == Ir).all() and (got16[0][:128] == Dr).all()
