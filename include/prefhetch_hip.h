@@ -183,7 +183,7 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *p
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 
 /* 16-bit operands for exactly-representable data.  When every value of the base matrix is an integer of magnitude <= 256
- * (checked on the device, value by value, by pf_flat_create; d a multiple of 64, d <= 256) the index keeps a bf16 image
+ * (checked on the device, value by value, by pf_flat_create; d = 64 or 128) the index keeps a bf16 image
  * of it, and pf_flat_search runs query tiles whose values pass the same check (again on the device, every search) through
  * the bf16 matrix instruction with fp32 accumulation: every product and every partial sum is then an integer below 2^24,
  * so the accumulator -- and with it every distance and every index -- is bit for bit what the fp32 loop returns.  Data

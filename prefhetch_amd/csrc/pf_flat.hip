@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
 
 // ---- bf16 operands for exactly-representable data --------------------------------------------------------------
 // SIFT-like vectors (the reference's dataset: 8-bit values stored as fp32) are integers of magnitude <= 256: exact in
-// bf16 (8 significant bits), every product x*y is an integer below 2^16 and, with d <= 256, every partial sum of a dot
-// product is an integer of magnitude <= 2^24 -- exactly representable in fp32.  The bf16 matrix instruction
+// bf16 (8 significant bits), every product x*y is an integer of at most 2^16 and, with d <= 128, every partial sum of a dot
+// product is an integer of magnitude <= 2^23 -- exactly representable in fp32.  The bf16 matrix instruction
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulation) therefore returns the same accumulator, bit for bit, as the k-ordered
 // fp32 fmaf chain of the f32 instruction, whatever order it adds in, at 16 times the rate; norms and the final
 // fmaf(-2, acc, |x|^2 + |y|^2) are computed by the same code on both paths.  Eligibility is CHECKED ON THE DEVICE, value by
@@ -72,25 +72,37 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
 // queries at the start of every search (per 128-query tile; a tile with an inexact value runs the fp32 loop).  Nothing is
 // assumed about the data, and a search needs no host synchronisation to pick its path.
 constexpr float BF16_EXACT_MAX = 256.f;
-constexpr uint32_t BF16_MAX_D = 256;
 __device__ __forceinline__ bool bf16_exact(float v) { return v == rintf(v) && fabsf(v) <= BF16_EXACT_MAX; }
 
-// row norms (fp32 fma chain in index order) + 16-bit image + eligibility; one thread per row
-__global__ void __launch_bounds__(256) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
-                                                   uint16_t *__restrict__ x16, uint32_t *__restrict__ inexact, uint32_t rows_per_flag) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float *r = x + i * d;
-    float acc = 0.f;
-    bool ok = true;
-    for (uint32_t k = 0; k < d; ++k) {
-        const float v = r[k];
-        acc = fmaf(v, v, acc);
-        ok = ok && bf16_exact(v);
-        if (x16) x16[i * d + k] = (uint16_t)(__float_as_uint(v) >> 16);       // exact when ok; unused otherwise
+// row norms (fp32 fma chain in index order) + 16-bit image + eligibility.  A workgroup of 64 threads takes 64 rows: the rows
+// are read coalesced (and converted / checked) by all lanes into LDS, then lane r chains row r's norm out of LDS (row pitch
+// d + 1 floats: conflict-free).  d <= PREP_MAX_D; wider rows take the one-thread-per-row kernel below.
+constexpr uint32_t PREP_MAX_D = 128;
+__global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
+                                                  uint16_t *__restrict__ x16, uint32_t *__restrict__ inexact, uint32_t rows_per_flag) {
+    __shared__ float tile[64 * (PREP_MAX_D + 1)];
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    const uint32_t rows = (uint32_t)(n - r0 < 64 ? n - r0 : 64), total = rows * d, lane = threadIdx.x;
+    const float *src = x + r0 * d;
+    uint32_t bad = 0;                                             // bit (row / rows_per_flag within this block's span) ... kept per lane
+    for (uint32_t e = lane; e < total; e += 64) {
+        const float v = src[e];
+        const uint32_t r = e / d, k = e - r * d;
+        tile[r * (d + 1) + k] = v;
+        if (x16) x16[r0 * d + e] = (uint16_t)(__float_as_uint(v) >> 16);      // exact when the value passes; unused otherwise
+        if (inexact && !bf16_exact(v)) bad |= 1u << (rows_per_flag ? ((r0 + r) / rows_per_flag - r0 / rows_per_flag) : 0);
     }
-    norms[i] = acc;
-    if (!ok && inexact) atomicOr(&inexact[rows_per_flag ? i / rows_per_flag : 0], 1u);
+    if (bad) {                                                    // a block of 64 rows touches at most two flags (rows_per_flag >= 64) or one
+        if (bad & 1u) atomicOr(&inexact[rows_per_flag ? r0 / rows_per_flag : 0], 1u);
+        if (bad & 2u) atomicOr(&inexact[r0 / rows_per_flag + 1], 1u);
+    }
+    __syncthreads();
+    if (lane < rows) {
+        const float *row = tile + lane * (d + 1);
+        float acc = 0.f;
+        for (uint32_t k = 0; k < d; ++k) acc = fmaf(row[k], row[k], acc);
+        norms[r0 + lane] = acc;
+    }
 }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -178,166 +190,38 @@ __device__ __forceinline__ void slab_commit(float *lds, const float4 (&v)[IT], i
     }
 }
 
-// AGG (the 32- and 64-row geometries): survivors are aggregated per row in LDS before the global append -- with few
-// queries the global counters are hot, and a workgroup there spans 256 columns of every row.
-// BF16 (batch geometry, d a multiple of 64, base image present): tiles whose queries are exactly representable run the
-// bf16 loop below instead of the fp32 slab loop; the epilogue is shared.
-constexpr int B16_KH = 64;                          // k-depth staged per step (d = 128: two steps)
-constexpr int B16_PITCH = B16_KH * 2 + 16;          // bytes per LDS row: 128 of data + 16 of padding (conflict-free b128 access)
-template <bool FILTER, class GEO, bool FAST, bool AGG = false, bool BF16 = false>   // AGG only matters with FILTER
-__global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
-    constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
-    constexpr size_t F32_BYTES = sizeof(float) * 2 * TK * (LDA + LDB), B16_BYTES = BF16 ? (size_t)(TM + TN) * B16_PITCH : 0;
-    __shared__ __align__(16) char smem[F32_BYTES > B16_BYTES ? F32_BYTES : B16_BYTES];
-    float (*sAb)[TK * LDA] = reinterpret_cast<float (*)[TK * LDA]>(smem);   // two k-slabs in flight: one feeds the MFMAs, the next is being filled
-    float (*sBb)[TK * LDB] = reinterpret_cast<float (*)[TK * LDB]>(smem + sizeof(float) * 2 * TK * LDA);
-    float *const sA = sAb[0];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
-    // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the base tile is
-    // fetched from HBM once into that XCD's L2 and re-read from there by the other query tiles.
-    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const uint32_t qt = j % p.n_qtiles, ct = (j / p.n_qtiles) * 8 + xcd;
-    const size_t q0 = (size_t)qt * TM;
-    const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
-    if (c0 >= p.nb_count) return;
-    const size_t q_valid = p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM;
-    const size_t c_valid = p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN;
-    const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-
-    // operands of the epilogue, requested now so that their latency hides under the whole tile: the norms of this lane's
-    // columns (NaN past the end of the chunk when filtering: such a distance compares false with every threshold) and,
-    // for the first TM threads, one query row's (norm, threshold)
-    size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        col[jj] = c0 + wn + 32 * jj + (lane & 31);
-        col_ok[jj] = col[jj] < p.nb_count;
-        bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : (FILTER ? __builtin_nanf("") : 0.f);
+// Epilogue of one distance tile, shared by the fp32 and the bf16 loops: acc = x.y of TM x TN (query, base row) pairs as the
+// 32x32 matrix instructions leave it, C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31].  `stage`: at least 4*TM floats
+// of LDS that no wave still reads.  Contains barriers (before any wave-uniform early return): call from all waves.
+// EXACT (the bf16 tiles: every quantity an integer below 2^24): dist <= tau  <=>  x.y >= (|x|^2 - tau)/2 + |y|^2/2, all three
+// terms and their sum exactly representable (half-integers of magnitude <= 2^23), so the first sweep compares the
+// accumulator with a per-(row, column) threshold -- one add and one compare per distance instead of add, fma, compare --
+// and returns the verdicts of the distance test bit for bit.  Keys are still built from the distance itself.
+// PRESTAGED: the caller has already written this query tile's rows to `sA` (l2_tile_stage_rows) and passed a barrier.
+template <class GEO, bool EXACT>
+__device__ __forceinline__ void l2_tile_stage_rows(float *sA, int tid, float row_qn, float row_tau) {
+    constexpr int TM = GEO::TM;
+    if (tid < TM) {                                              // (norm, threshold) pairs: one 8-byte LDS read per use
+        sA[2 * tid] = row_qn;
+        sA[2 * tid + 1] = row_tau;
+        if constexpr (EXACT) sA[3 * TM + tid] = 0.5f * (row_qn - row_tau);   // +inf for rows past nq (tau = -inf): nothing passes
+        reinterpret_cast<uint32_t *>(sA)[2 * TM + tid] = 0;     // per-row survivor count of this workgroup (small batches)
     }
-    float row_qn = 0.f, row_tau = -INFINITY;                      // rows past nq: nothing passes
-    if constexpr (FILTER) {
-        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
-    }
-    bool f32_loop = true;
-    if constexpr (BF16) {
-        static_assert(TM == 128 && TN == 128 && GEO::THREADS == 256, "the bf16 loop is written for the batch geometry");
-        if (p.q_inexact[qt] == 0) {                                   // workgroup-uniform
-            f32_loop = false;
-            char *const sA16 = smem, *const sB16 = smem + TM * B16_PITCH;
-            // staging: a row's 128 bytes are covered by 8 lanes x 16 bytes; rows past the end re-read the last valid row
-            // (their products land in accumulator rows / columns the epilogue never emits)
-            const int srow = tid >> 3, sseg = tid & 7;
-            uint32_t oa[4], ob[4];                                    // element offsets from the tile's first row (32 bits: a tile spans < 2^31 elements)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t ra_ = (size_t)(srow + 32 * it) < q_valid ? srow + 32 * it : (uint32_t)q_valid - 1;
-                const uint32_t rb_ = (size_t)(srow + 32 * it) < c_valid ? srow + 32 * it : (uint32_t)c_valid - 1;
-                oa[it] = ra_ * p.d + sseg * 8;
-                ob[it] = rb_ * p.d + sseg * 8;
-            }
-            const uint16_t *const abase = p.xq16 + q0 * (size_t)p.d, *const bbase = p.xb16 + (p.nb_first + c0) * (size_t)p.d;
-            // One k-step of 64 at a time, operands held in registers only between the load and the LDS write: the four
-            // workgroups resident on a CU cover each other's load latency, and the registers go to occupancy instead of a
-            // second operand set (with one, hipcc spilled it -- every load followed by a wait and a scratch store)
-            for (uint32_t k0 = 0; k0 < p.d; k0 += B16_KH) {
-                u32x4 va[4], vb[4];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    va[it] = *reinterpret_cast<const u32x4 *>(abase + oa[it] + k0);
-                    vb[it] = *reinterpret_cast<const u32x4 *>(bbase + ob[it] + k0);
-                }
-                if (k0) __syncthreads();                              // the previous step's fragments have been read
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    *reinterpret_cast<u32x4 *>(sA16 + (srow + 32 * it) * B16_PITCH + sseg * 16) = va[it];
-                    *reinterpret_cast<u32x4 *>(sB16 + (srow + 32 * it) * B16_PITCH + sseg * 16) = vb[it];
-                }
-                __syncthreads();
-                // lane l feeds row (l & 31), k = 8 * (l >> 5) .. + 7 of every 16-deep step: 16 contiguous bytes of an LDS row
-                const char *fa = sA16 + (wm + (lane & 31)) * B16_PITCH + (lane >> 5) * 16;
-                const char *fb = sB16 + (wn + (lane & 31)) * B16_PITCH + (lane >> 5) * 16;
-#pragma unroll
-                for (int ks = 0; ks < B16_KH / 16; ++ks) {
-                    bf16x8 a[MI], b[NJ];
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(fa + 32 * i * B16_PITCH + ks * 32);
-#pragma unroll
-                    for (int jj = 0; jj < NJ; ++jj) b[jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * B16_PITCH + ks * 32);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (f32_loop) {
-    float4 ra[GEO::ITA], rb[GEO::ITB];
-    slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
-    slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
-    slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[0], ra, tid);
-    slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[0], rb, tid);
-    if (TK < p.d) {
-        slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, TK, tid);
-        slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, TK, tid);
-    }
-    __syncthreads();
-    // slab s feeds the matrix pipe from buffer s&1 while slab s+1 (in registers since the previous iteration) is
-    // committed to the other buffer and slab s+2 is requested from memory: one barrier per slab
-    for (uint32_t k0 = 0, cur = 0; k0 < p.d; k0 += TK, cur ^= 1) {
-        if (k0 + TK < p.d) {
-            slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[cur ^ 1], ra, tid);
-            slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[cur ^ 1], rb, tid);
-            if (k0 + 2 * TK < p.d) {
-                slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + 2 * TK, tid);
-                slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + 2 * TK, tid);
-            }
-        }
-        // operand fragments of k-step s+1 are read from LDS while the MFMAs of step s run
-        float a[2][MI], b[2][NJ];
-        const float *fa = sAb[cur] + (lane >> 5) * LDA + wm + (lane & 31), *fb = sBb[cur] + (lane >> 5) * LDB + wn + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[0][i] = fa[32 * i];
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) b[0][jj] = fb[32 * jj];
-#pragma unroll
-        for (int ks = 0; ks < TK; ks += 2) {
-            const int cur = (ks >> 1) & 1, nxt = cur ^ 1;
-            if (ks + 2 < TK) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[nxt][i] = fa[(ks + 2) * LDA + 32 * i];
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) b[nxt][jj] = fb[(ks + 2) * LDB + 32 * jj];
-            }
-            __builtin_amdgcn_sched_barrier(0);         // keep the reads ahead of the MFMAs they overlap with
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-    }   // f32_loop
+}
+template <bool FILTER, class GEO, bool AGG, bool EXACT = false, bool PRESTAGED = false>
+__device__ __forceinline__ void l2_tile_epilogue(const TileArgs &p, f32x16 (&acc)[GEO::MI][GEO::NJ], float *sA, size_t q0, int wm, int tid,
+                                                 const size_t (&col)[GEO::NJ], const bool (&col_ok)[GEO::NJ], const float (&bnv)[GEO::NJ],
+                                                 float row_qn, float row_tau) {
+    constexpr int TM = GEO::TM, MI = GEO::MI, NJ = GEO::NJ;
+    const int lane = tid & 63;
     // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     if constexpr (FILTER) {
         // per-query norm and threshold of this tile's rows, staged in LDS (sA is free now)
-        __syncthreads();
-        if (tid < TM) {                                              // (norm, threshold) pairs: one 8-byte LDS read per use
-            sA[2 * tid] = row_qn;
-            sA[2 * tid + 1] = row_tau;
-            reinterpret_cast<uint32_t *>(sA)[2 * TM + tid] = 0;     // per-row survivor count of this workgroup (small batches)
+        if constexpr (!PRESTAGED) {
+            __syncthreads();
+            l2_tile_stage_rows<GEO, EXACT>(sA, tid, row_qn, row_tau);
+            __syncthreads();
         }
-        __syncthreads();
     }
     if constexpr (FILTER && AGG) {
         // Small batches: few queries take every survivor of the chunk, so one global atomic per half-wave would
@@ -414,6 +298,9 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
         // non-zero count reserves its row's range with one atomic -- all rows of the wave in ONE memory round trip instead
         // of one dependent round trip per row.  Second sweep, only over registers that had survivors: write the keys.
         uint32_t row_cnt = 0, hit[MI];
+        float bnh[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) bnh[jj] = 0.5f * bnv[jj];        // NaN past the end of the chunk: compares false
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             hit[i] = 0;
@@ -421,17 +308,24 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             for (int r8 = 0; r8 < 16; r8 += 8) {
             // (norm, threshold) pairs of eight registers fetched from LDS together: one latency per batch
             float2 qts[8];
+            float rqs[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                qts[e] = *reinterpret_cast<const float2 *>(sA + 2 * (wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)));
+            for (int e = 0; e < 8; ++e) {
+                const int lrow = wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5);
+                if constexpr (EXACT) rqs[e] = sA[3 * TM + lrow];
+                else qts[e] = *reinterpret_cast<const float2 *>(sA + 2 * lrow);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = r8 + e;
                 uint64_t m[NJ], any = 0;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
-                    const float dist = fmaf(-2.f, acc[i][jj][r], qts[e].x + bnv[jj]);
-                    m[jj] = __ballot(dist <= qts[e].y);                  // tau >= 0: same verdict before and after the clamp at 0
+                    if constexpr (EXACT) m[jj] = __ballot(acc[i][jj][r] >= rqs[e] + bnh[jj]);
+                    else {
+                        const float dist = fmaf(-2.f, acc[i][jj][r], qts[e].x + bnv[jj]);
+                        m[jj] = __ballot(dist <= qts[e].y);              // tau >= 0: same verdict before and after the clamp at 0
+                    }
                     any |= m[jj];
                 }
                 if (any == 0) continue;                                  // wave-uniform, and the common case in late chunks
@@ -499,6 +393,338 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
             }
         }
     }
+}
+
+// One fp32 distance tile (query tile qt, column tile ct of the chunk): body of k_l2_tile, also the fallback of the bf16
+// kernel for query tiles that are not exactly representable.  smem: F32_TILE_LDS<GEO> bytes, 16-byte aligned.
+template <class GEO> constexpr size_t F32_TILE_LDS = sizeof(float) * 2 * TK * (GEO::LDA + GEO::LDB);
+template <bool FILTER, class GEO, bool FAST, bool AGG>
+__device__ __forceinline__ void l2_tile_f32(const TileArgs &p, char *smem, uint32_t qt, uint32_t ct) {
+    constexpr int TM = GEO::TM, TN = GEO::TN, LDA = GEO::LDA, LDB = GEO::LDB, MI = GEO::MI, NJ = GEO::NJ, RPI = GEO::ROWS_PER_IT;
+    float (*sAb)[TK * LDA] = reinterpret_cast<float (*)[TK * LDA]>(smem);   // two k-slabs in flight: one feeds the MFMAs, the next is being filled
+    float (*sBb)[TK * LDB] = reinterpret_cast<float (*)[TK * LDB]>(smem + sizeof(float) * 2 * TK * LDA);
+    float *const sA = sAb[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t q0 = (size_t)qt * TM;
+    const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
+    if (c0 >= p.nb_count) return;
+    const size_t q_valid = p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM;
+    const size_t c_valid = p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN;
+    const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // operands of the epilogue, requested now so that their latency hides under the whole tile: the norms of this lane's
+    // columns (NaN past the end of the chunk when filtering: such a distance compares false with every threshold) and,
+    // for the first TM threads, one query row's (norm, threshold)
+    size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        col[jj] = c0 + wn + 32 * jj + (lane & 31);
+        col_ok[jj] = col[jj] < p.nb_count;
+        bnv[jj] = col_ok[jj] ? p.bn[p.nb_first + col[jj]] : (FILTER ? __builtin_nanf("") : 0.f);
+    }
+    float row_qn = 0.f, row_tau = -INFINITY;                      // rows past nq: nothing passes
+    if constexpr (FILTER) {
+        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
+    }
+    float4 ra[GEO::ITA], rb[GEO::ITB];
+    slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, 0, tid);
+    slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, 0, tid);
+    slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[0], ra, tid);
+    slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[0], rb, tid);
+    if (TK < p.d) {
+        slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, TK, tid);
+        slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, TK, tid);
+    }
+    __syncthreads();
+    // slab s feeds the matrix pipe from buffer s&1 while slab s+1 (in registers since the previous iteration) is
+    // committed to the other buffer and slab s+2 is requested from memory: one barrier per slab
+    for (uint32_t k0 = 0, cur = 0; k0 < p.d; k0 += TK, cur ^= 1) {
+        if (k0 + TK < p.d) {
+            slab_commit<TM, GEO::ITA, RPI, LDA>(sAb[cur ^ 1], ra, tid);
+            slab_commit<TN, GEO::ITB, RPI, LDB>(sBb[cur ^ 1], rb, tid);
+            if (k0 + 2 * TK < p.d) {
+                slab_fetch<FAST, TM, GEO::ITA, RPI>(ra, p.xq, q0, q_valid, p.d, k0 + 2 * TK, tid);
+                slab_fetch<FAST, TN, GEO::ITB, RPI>(rb, p.xb, p.nb_first + c0, c_valid, p.d, k0 + 2 * TK, tid);
+            }
+        }
+        // operand fragments of k-step s+1 are read from LDS while the MFMAs of step s run
+        float a[2][MI], b[2][NJ];
+        const float *fa = sAb[cur] + (lane >> 5) * LDA + wm + (lane & 31), *fb = sBb[cur] + (lane >> 5) * LDB + wn + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = fa[32 * i];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) b[0][jj] = fb[32 * jj];
+#pragma unroll
+        for (int ks = 0; ks < TK; ks += 2) {
+            const int cur = (ks >> 1) & 1, nxt = cur ^ 1;
+            if (ks + 2 < TK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[nxt][i] = fa[(ks + 2) * LDA + 32 * i];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) b[nxt][jj] = fb[(ks + 2) * LDB + 32 * jj];
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads ahead of the MFMAs they overlap with
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    l2_tile_epilogue<FILTER, GEO, AGG>(p, acc, sA, q0, wm, tid, col, col_ok, bnv, row_qn, row_tau);
+}
+
+// AGG (the 32- and 64-row geometries): survivors are aggregated per row in LDS before the global append -- with few
+// queries the global counters are hot, and a workgroup there spans 256 columns of every row.
+template <bool FILTER, class GEO, bool FAST, bool AGG = false>   // AGG only matters with FILTER
+__global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
+    __shared__ __align__(16) char smem[F32_TILE_LDS<GEO>];
+    // XCD-aware tile order (1-D grid): blocks b and b+8 share an XCD under round-robin placement, so XCD x takes the
+    // column tiles = x (mod 8) and runs all query tiles of one column tile back to back -- the base tile is
+    // fetched from HBM once into that XCD's L2 and re-read from there by the other query tiles.
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    l2_tile_f32<FILTER, GEO, FAST, AGG>(p, smem, j % p.n_qtiles, (j / p.n_qtiles) * 8 + xcd);
+}
+
+// Survivors of the bf16 tiles are parked in LDS and written out once per workgroup walk instead of once per tile.  The
+// fp32 epilogue reserves room in the candidate lists with a returning global atomic per wave and tile and sweeps the
+// accumulators twice; at two workgroups per CU nothing covers that round trip (measured by elimination: the tile loop
+// without any epilogue 0.48 ms per search, with the threshold sweep alone 0.59, with reservation and second sweep 0.85).
+// Here a survivor costs one LDS atomic (its slot in the list) in the one sweep that finds it; row-local indices and the
+// global reservation -- one atomic per row with survivors -- are dealt with by flush(), once per walk or when the list
+// runs full.  A survivor that finds the list full (dense early chunks) is appended in global memory on the spot.
+struct Pend16 {
+    static constexpr uint32_t CAP = 704;      // 2 x 34 KiB of operands + 1 KiB of rows + this list fit twice into a CU's 160 KiB
+    uint64_t key[CAP];
+    uint32_t loc[CAP];                 // local row; flush() adds the row-local index in the upper half
+    uint32_t rcnt[128], rbase[128];
+    uint32_t n;
+};
+
+template <class GEO>
+__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, size_t q0, int tid) {
+    __syncthreads();                                              // every append has landed
+    const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;   // adds beyond the capacity went to global memory directly
+    if (n == 0) return;                                           // workgroup-uniform
+    for (uint32_t e = tid; e < n; e += GEO::THREADS) {
+        const uint32_t row = pd.loc[e];
+        pd.loc[e] = row | (atomicAdd(&pd.rcnt[row], 1u) << 16);
+    }
+    __syncthreads();
+    if (tid < GEO::TM) {
+        const uint32_t c = pd.rcnt[tid];
+        pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
+        pd.rcnt[tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < n; e += GEO::THREADS) {
+        const uint32_t loc = pd.loc[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
+        if (pos < p.cap) p.cand[(q0 + row) * p.cap + pos] = pd.key[e];
+    }
+    __syncthreads();
+    if (tid == 0) pd.n = 0;
+    __syncthreads();
+}
+
+// FILTER epilogue of the bf16 tiles (EXACT thresholds, rows prestaged in `sA`: (norm, threshold) pairs and, at 3*TM, the
+// accumulator thresholds).  No barrier inside: the caller's per-tile barrier follows.
+template <class GEO>
+__device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&acc)[GEO::MI][GEO::NJ], const float *sA, Pend16 &pd, size_t q0,
+                                                   int wm, int tid, const size_t (&col)[GEO::NJ], const float (&bnv)[GEO::NJ]) {
+    constexpr int TM = GEO::TM, MI = GEO::MI, NJ = GEO::NJ;
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));       // opaque per call: or hipcc computes the 32 local-row numbers of this lane once, ahead of the
+                                         // caller's tile loop, and keeps them in 32 registers across it (spills)
+    float bnh[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) bnh[jj] = 0.5f * bnv[jj];            // NaN past the end of the chunk: compares false
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+            float rqs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rqs[e] = sA[3 * TM + wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r8 + e;
+                bool pass[NJ];
+                uint64_t any = 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) { pass[jj] = acc[i][jj][r] >= rqs[e] + bnh[jj]; any |= __ballot(pass[jj]); }
+                if (any == 0) continue;                                  // wave-uniform, and the common case in late chunks
+                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float qn = sA[2 * lrow];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    if (!pass[jj]) continue;
+                    const float dist = fmaf(-2.f, acc[i][jj][r], qn + bnv[jj]);      // exact data: dist <= tau is the verdict above
+                    const uint64_t key = make_key(dist < 0.f ? 0.f : dist, (uint32_t)(p.nb_first + col[jj]));
+                    const uint32_t e2 = atomicAdd(&pd.n, 1u);
+                    if (e2 < Pend16::CAP) { pd.key[e2] = key; pd.loc[e2] = (uint32_t)lrow; }
+                    else {                                               // list full: straight to the candidate list
+                        const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
+                        if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = key;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- bf16 tiles (exactly-representable data, d = 64 or 128) ---------------------------------------------------------
+// One workgroup keeps the bf16 image of its 128-query tile in LDS (whole k) and walks `group` consecutive 128-row column
+// tiles: while the matrix pipe and the epilogue work on tile t, the global loads of tile t+1 are in flight in registers.
+// Per tile that leaves an LDS write, two barriers, 32 matrix instructions per wave and the filtering epilogue; the query
+// tile is fetched once per `group` tiles.  LDS rows carry 16 bytes of padding: conflict-free ds_write_b128 / ds_read_b128.
+// A query tile with a value that is NOT exactly representable (q_inexact, set on the device) runs the fp32 tile body here.
+template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
+__global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
+    using GEO = GeoBatch;
+    constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = 128 * 2 + 16;
+    static_assert(F32_TILE_LDS<GEO> <= (size_t)(TM + TN) * PITCH, "the fp32 fallback borrows the bf16 tiles' LDS");
+    __shared__ __align__(16) char smem[(TM + TN) * PITCH];
+    __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
+    __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint32_t qt = j % p.n_qtiles, grp = (j / p.n_qtiles) * 8 + xcd;
+    if (grp >= n_groups) return;
+    if constexpr (FILTER) {
+        if (tid < TM) pend.rcnt[tid] = 0;
+        if (tid == 0) pend.n = 0;
+    }
+    const uint32_t n_ct = (uint32_t)((p.nb_count + TN - 1) / TN);
+    const uint32_t ct0 = grp * group, ct1 = ct0 + group < n_ct ? ct0 + group : n_ct;
+    if (p.q_inexact[qt]) {                                          // workgroup-uniform: fp32 operands for this query tile
+        for (uint32_t ct = ct0; ct < ct1; ++ct) {
+#ifndef PF_DBG_NO_FALLBACK
+            l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
+#endif
+            __syncthreads();
+        }
+        return;
+    }
+    const size_t q0 = (size_t)qt * TM;
+    const uint32_t q_valid = (uint32_t)(p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM);
+    const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);
+    char *const sB16_0 = smem, *const sB16_1 = smem + TN * PITCH;   // column tiles alternate between two buffers: ONE barrier per tile
+    // The query operand never changes during the walk: each wave keeps its fragments in registers (lane l: row l & 31 of each
+    // 32-row block, 8 consecutive k of every 16-deep step = 16 bytes of the bf16 row image; rows past the end re-read the last
+    // valid row -- their products land in accumulator rows the epilogue never emits)
+    bf16x8 afrag[MI][D / 16];
+    {
+        const uint16_t *abase = p.xq16 + q0 * (size_t)D;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const uint32_t r = wm + 32 * i + (lane & 31);
+            const uint16_t *row = abase + (r < q_valid ? r : q_valid - 1) * D + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) afrag[i][ks] = *reinterpret_cast<const bf16x8 *>(row + ks * 16);
+        }
+    }
+    float row_qn = 0.f, row_tau = -INFINITY;                        // rows past nq: nothing passes
+    if constexpr (FILTER) {
+        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
+        // the rows of the query tile are the same for every column tile: staged once
+        l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
+    }
+    // staging of a column tile: 16 bytes per lane, a row of D*2 bytes covered by D/8 consecutive lanes
+    constexpr uint32_t segs = D / 8, rows_per_sweep = 256 / segs, sweeps = TN / rows_per_sweep;     // D = 128: 16, 16, 8
+    const uint32_t srow = tid / segs, sseg = tid % segs;
+    u32x4 vb[sweeps];
+    float bn_next[NJ];
+    // operands AND column norms of a tile are requested one tile ahead of their LDS write, two tiles ahead of their use
+    auto fetch_b = [&](uint32_t ct) {
+        const size_t c0 = (size_t)ct * TN;
+        const uint32_t c_valid = (uint32_t)(p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN);
+        const uint16_t *bbase = p.xb16 + (p.nb_first + c0) * (size_t)D;
+#pragma unroll
+        for (uint32_t it = 0; it < sweeps; ++it) {
+            const uint32_t r = srow + rows_per_sweep * it;
+            vb[it] = *reinterpret_cast<const u32x4 *>(bbase + (r < c_valid ? r : c_valid - 1) * D + sseg * 8);
+        }
+    };
+    auto fetch_bn = [&](uint32_t ct) {
+        const size_t c0 = (size_t)ct * TN;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const size_t c = c0 + wn + 32 * jj + (lane & 31);
+            bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : (FILTER ? __builtin_nanf("") : 0.f);
+        }
+    };
+    auto commit_b = [&](char *buf) {
+#pragma unroll
+        for (uint32_t it = 0; it < sweeps; ++it) *reinterpret_cast<u32x4 *>(buf + (srow + rows_per_sweep * it) * PITCH + sseg * 16) = vb[it];
+    };
+    fetch_b(ct0);
+    fetch_bn(ct0);
+    commit_b(sB16_0);
+    if (ct0 + 1 < ct1) fetch_b(ct0 + 1);
+    __syncthreads();
+    for (uint32_t ct = ct0; ct < ct1; ++ct) {
+        const uint32_t cur = (ct - ct0) & 1u;
+        // tile ct+1 goes into the other buffer: its last readers (tile ct-1) passed the barrier that ended that tile
+        if (ct + 1 < ct1) commit_b(cur ? sB16_0 : sB16_1);
+        const size_t c0 = (size_t)ct * TN;
+        size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            col[jj] = c0 + wn + 32 * jj + (lane & 31);
+            col_ok[jj] = col[jj] < p.nb_count;
+            bnv[jj] = bn_next[jj];
+        }
+        if (ct + 2 < ct1) fetch_b(ct + 2);                          // in flight under this tile's matrix work and epilogue
+        if (ct + 1 < ct1) fetch_bn(ct + 1);
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+        // column fragments of k-step s+1 are read from LDS while the matrix instructions of step s run (fenced: left to
+        // itself hipcc hoists every fragment read of the tile to the top)
+        const char *fb = (cur ? sB16_1 : sB16_0) + (wn + (lane & 31)) * PITCH + (lane >> 5) * 16;
+        bf16x8 b[2][NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) b[0][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH);
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const int c = ks & 1, n = c ^ 1;
+            if (ks + 1 < D / 16) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH + (ks + 1) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // q0 made opaque per tile: otherwise hipcc hoists the row addresses (q0 + row) * cap of the (rare) key stores out of
+        // the tile loop and keeps them alive across it
+        size_t q0t = q0;
+        asm volatile("" : "+s"(q0t));
+        if constexpr (FILTER) {
+            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, bnv);
+            __syncthreads();                                        // the tile's one barrier: the other buffer is complete, the list settled
+            if (pend.n > Pend16::CAP / 2) pend16_flush<GEO>(p, pend, q0, tid);   // workgroup-uniform
+        } else {
+            l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
+            __syncthreads();
+        }
+    }
+    if constexpr (FILTER) pend16_flush<GEO>(p, pend, q0, tid);
 }
 
 // ---- selection -----------------------------------------------------------------------------------
@@ -849,6 +1075,7 @@ struct pf_flat {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     size_t wg_slots = 1024;   // workgroups of the tile kernel resident on the device at once (CUs x occupancy)
+    size_t num_cus = 256;
 };
 
 namespace {
@@ -933,14 +1160,15 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     if (e == hipSuccess && nb) {
         // row norms; and, where the shape allows the bf16 loop, the 16-bit image with its value-by-value exactness check
         uint32_t *flag = nullptr;
-        const bool try16 = d % B16_KH == 0 && d <= BF16_MAX_D && getenv("PF_FLAT_NO_BF16") == nullptr;
+        const bool try16 = (d == 64 || d == 128) && getenv("PF_FLAT_NO_BF16") == nullptr;
         if (try16 && (hipMalloc((void **)&f->xb16, nb * (size_t)d * 2) != hipSuccess || hipMalloc((void **)&flag, 4) != hipSuccess ||
                       hipMemset(flag, 0, 4) != hipSuccess)) {
             (void)hipGetLastError();                                  // no room for the image: the fp32 path needs none
             if (f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }
             if (flag) { (void)hipFree(flag); flag = nullptr; }
         }
-        hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, flag, 0u);
+        if (d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, flag, 0u);
+        else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (flag) {
@@ -952,11 +1180,12 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     }
     if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
     {
-        hipDeviceProp_t prop;
+        hipDeviceProp_t prop{};
         int occ = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_l2_tile<true, GeoBatch, true>, 256, 0) == hipSuccess && occ > 0)
             f->wg_slots = (size_t)prop.multiProcessorCount * (size_t)occ;
+        if (prop.multiProcessorCount > 0) f->num_cus = (size_t)prop.multiProcessorCount;
         (void)hipGetLastError();
     }
     *out = f;
@@ -1011,8 +1240,9 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
     if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
-    hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr,
-                       b16 ? qbad : nullptr, 128u);
+    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr,
+                                               b16 ? qbad : nullptr, 128u);
+    else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
     t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
@@ -1027,6 +1257,22 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
+        if (b16) {
+            // column tiles per workgroup: as many as keep every workgroup slot of the device (2 per CU) busy, at most 8
+            size_t group = nct * t.n_qtiles / (2 * (size_t)f->num_cus * 2);
+            group = group < 1 ? 1 : group > 8 ? 8 : group;
+            const size_t n_groups = (nct + group - 1) / group;
+            const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
+            const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
+            if (f->d == 128) {
+                if (filter) hipLaunchKernelGGL((k_l2_tile16<true, 128>), grid16, dim3(256), 0, s, t, g32, n32);
+                else hipLaunchKernelGGL((k_l2_tile16<false, 128>), grid16, dim3(256), 0, s, t, g32, n32);
+            } else {
+                if (filter) hipLaunchKernelGGL((k_l2_tile16<true, 64>), grid16, dim3(256), 0, s, t, g32, n32);
+                else hipLaunchKernelGGL((k_l2_tile16<false, 64>), grid16, dim3(256), 0, s, t, g32, n32);
+            }
+            return;
+        }
         const dim3 grid((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles));
         const bool fast = f->d % TK == 0;
 #define PF_TILE(FILTER, GEO, AGG) do { if (fast) hipLaunchKernelGGL((k_l2_tile<FILTER, GEO, true, AGG>), grid, dim3(256), 0, s, t); \
@@ -1039,12 +1285,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             case 1: if (agg) PF_TILE(true, GeoSmall32, true); else PF_TILE(true, GeoSmall32, false); break;
             case 2: PF_TILE(false, GeoSmall64, false); break;
             case 3: PF_TILE(true, GeoSmall64, true); break;
-            case 4: if (b16) hipLaunchKernelGGL((k_l2_tile<false, GeoBatch, true, false, true>), grid, dim3(256), 0, s, t);
-                    else PF_TILE(false, GeoBatch, false);
-                    break;
-            default: if (b16) hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, true, false, true>), grid, dim3(256), 0, s, t);
-                     else PF_TILE(true, GeoBatch, false);
-                     break;
+            case 4: PF_TILE(false, GeoBatch, false); break;
+            default: PF_TILE(true, GeoBatch, false); break;
         }
 #undef PF_TILE
     };
@@ -1062,7 +1304,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     // the candidate capacity
     size_t pos = boot;
     while (pos < f->nb) {
-        size_t chunk = pos * w.cap / (4 * (size_t)k);
+        static const size_t growth_div = getenv("PF_FLAT_GROWTH_DIV") ? (size_t)atoi(getenv("PF_FLAT_GROWTH_DIV")) : 4;   // experiments
+        size_t chunk = pos * w.cap / (growth_div * (size_t)k);
         chunk = chunk / 256 * 256;
         if (chunk < 4096) chunk = 4096;
         if (chunk > MAX_CHUNK && geo == 2) chunk = MAX_CHUNK;       // few queries: fewer, longer launches (each one has a ramp and a merge)

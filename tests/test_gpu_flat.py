@@ -317,7 +317,7 @@ def _search_both(pf, xb, xq, k):
     return active, (D1.cpu().numpy(), I1.cpu().numpy()), (D0.cpu().numpy(), I0.cpu().numpy())
 
 
-@pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (192, 70, 100), (256, 128, 64)])
+@pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (128, 1024, 100), (64, 65, 64)])
 def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
     """exactly-representable data (integers, |v| <= 256): the bf16-operand tiles must return the fp32 loop's (D, I) and the
     oracle's, bit for bit -- including the extreme values +-256 and heavy ties"""
@@ -353,7 +353,8 @@ def test_exact16_path_refuses_inexact_data():
         xb[1234, 77] = bad
         assert not pf.FlatL2(xb, dev).exact16()
     assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
-    assert not pf.FlatL2(rng.integers(0, 256, (500, 100)).astype(np.float32), dev).exact16()      # d not a multiple of 64
+    for d in (100, 192, 256):                                                                          # row lengths the bf16 tiles are not built for
+        assert not pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).exact16()
     assert pf.FlatL2(base, dev).exact16()
 
 
