@@ -39,7 +39,7 @@ class Server {
     // ../sift/siftsmall/siftsmall_base.fvecs and writes the cache; otherwise loads base + cache.  The cache is this
     // build's own format (the reference's is faiss::write_index).  k-means assignments run on the GPU flat index.
     void init_index();
-    // Serves the four routes through Drogon when built with -DPREFHETCH_WITH_DROGON; otherwise throws.
+    // Serves the routes over HTTP/1.1 on 0.0.0.0:8080 (reference :48-53) with the POSIX-socket listener of http.h; blocks.
     void run_webserver();
 
     void retrieve_centroids(std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> &centroids) const;

@@ -1,0 +1,222 @@
+// http.cpp -- POSIX-socket HTTP/1.1 listener and client for the PreFHEtch routes (include/server/http.h).
+#include "http.h"
+
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <stdexcept>
+
+namespace wire {
+
+namespace {
+
+bool send_all(int fd, const char *p, size_t n) {
+    while (n) {
+        const ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); }); return s; }
+
+// One HTTP message off a socket: start line, headers (lower-cased names), body by Content-Length.  `buf` carries bytes
+// read past the previous message (keep-alive).  Returns false on EOF / error before a complete head.
+struct Message { std::string start; std::vector<std::pair<std::string, std::string>> headers; std::string body; };
+enum class Recv { Ok, Closed, Bad, TooLarge };
+
+const std::string *header(const Message &m, const char *name) {
+    for (const auto &h : m.headers) if (h.first == name) return &h.second;
+    return nullptr;
+}
+
+bool fill(int fd, std::string &buf) {
+    char tmp[65536];
+    for (;;) {
+        const ssize_t r = ::recv(fd, tmp, sizeof tmp, 0);
+        if (r > 0) { buf.append(tmp, (size_t)r); return true; }
+        if (r < 0 && errno == EINTR) continue;
+        return false;
+    }
+}
+
+// on_head: called once the head is parsed and before the body is read (the server answers "Expect: 100-continue" there)
+Recv read_message(int fd, std::string &buf, Message &m, size_t max_body, const std::function<void(const Message &)> &on_head) {
+    size_t end;
+    while ((end = buf.find("\r\n\r\n")) == std::string::npos) {
+        if (buf.size() > (1u << 20)) return Recv::Bad;
+        if (!fill(fd, buf)) return buf.empty() ? Recv::Closed : Recv::Bad;
+    }
+    const std::string head = buf.substr(0, end);
+    buf.erase(0, end + 4);
+    size_t pos = head.find("\r\n");
+    m.start = head.substr(0, pos);
+    m.headers.clear();
+    while (pos != std::string::npos) {
+        const size_t next = head.find("\r\n", pos + 2);
+        const std::string line = head.substr(pos + 2, next == std::string::npos ? std::string::npos : next - pos - 2);
+        const size_t colon = line.find(':');
+        if (colon == std::string::npos) { if (!line.empty()) return Recv::Bad; }
+        else {
+            size_t v = colon + 1;
+            while (v < line.size() && (line[v] == ' ' || line[v] == '\t')) ++v;
+            m.headers.emplace_back(lower(line.substr(0, colon)), line.substr(v));
+        }
+        pos = next;
+    }
+    size_t len = 0;
+    if (const std::string *cl = header(m, "content-length")) {
+        if (cl->empty() || cl->find_first_not_of("0123456789") != std::string::npos || cl->size() > 18) return Recv::Bad;
+        len = (size_t)std::stoull(*cl);
+    } else if (header(m, "transfer-encoding")) return Recv::Bad;             // chunked bodies: not spoken here
+    if (len > max_body) return Recv::TooLarge;
+    if (on_head) on_head(m);
+    while (buf.size() < len) if (!fill(fd, buf)) return Recv::Bad;
+    m.body = buf.substr(0, len);
+    buf.erase(0, len);
+    return Recv::Ok;
+}
+
+void respond(int fd, int status, const char *reason, const std::string &body, bool keep_alive, const char *type = "application/json") {
+    std::string head = "HTTP/1.1 " + std::to_string(status) + " " + reason + "\r\nContent-Type: " + type + "\r\nContent-Length: " +
+                       std::to_string(body.size()) + "\r\nConnection: " + (keep_alive ? "keep-alive" : "close") + "\r\n\r\n";
+    if (send_all(fd, head.data(), head.size())) send_all(fd, body.data(), body.size());
+}
+
+}  // namespace
+
+HttpListener::HttpListener(HttpHandler handler, const std::string &address, uint16_t port, size_t max_body)
+    : m_Handler(std::move(handler)), m_MaxBody(max_body) {
+    m_Fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (m_Fd < 0) throw std::runtime_error(std::string("HttpListener: socket: ") + std::strerror(errno));
+    int one = 1;
+    ::setsockopt(m_Fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    sockaddr_in a{};
+    a.sin_family = AF_INET;
+    a.sin_port = htons(port);
+    if (::inet_pton(AF_INET, address.c_str(), &a.sin_addr) != 1) { ::close(m_Fd); throw std::runtime_error("HttpListener: bad IPv4 address " + address); }
+    if (::bind(m_Fd, reinterpret_cast<sockaddr *>(&a), sizeof a) < 0 || ::listen(m_Fd, 64) < 0) {
+        const std::string why = std::strerror(errno);
+        ::close(m_Fd);
+        throw std::runtime_error("HttpListener: cannot listen on " + address + ":" + std::to_string(port) + ": " + why);
+    }
+    socklen_t sl = sizeof a;
+    ::getsockname(m_Fd, reinterpret_cast<sockaddr *>(&a), &sl);
+    m_Port = ntohs(a.sin_port);
+}
+
+HttpListener::HttpListener(Server &server, const std::string &address, uint16_t port)
+    : HttpListener([&server](const std::string &, const std::string &route, const std::string &body) { return handle(server, route, body); },
+                   address, port) {}
+
+HttpListener::~HttpListener() { if (m_Fd >= 0) ::close(m_Fd); }
+
+void HttpListener::stop() { m_Stop = true; }
+
+size_t HttpListener::serve(size_t max_requests) {
+    size_t served = 0;
+    while (!m_Stop && (max_requests == 0 || served < max_requests)) {
+        pollfd pfd{m_Fd, POLLIN, 0};
+        const int pr = ::poll(&pfd, 1, 100);                         // wakes up to look at the stop flag
+        if (pr <= 0) continue;
+        const int c = ::accept(m_Fd, nullptr, nullptr);
+        if (c < 0) continue;
+        int one = 1;
+        ::setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        std::string buf;
+        while (!m_Stop && (max_requests == 0 || served < max_requests)) {
+            pollfd cp{c, POLLIN, 0};
+            if (buf.empty()) {                                       // idle keep-alive connection: do not block the listener for ever
+                const int r = ::poll(&cp, 1, 100);
+                if (r == 0) { if (m_Stop) break; continue; }
+                if (r < 0) break;
+            }
+            Message m;
+            const Recv rc = read_message(c, buf, m, m_MaxBody, [c](const Message &head) {
+                const std::string *e = header(head, "expect");
+                if (e && lower(*e) == "100-continue") send_all(c, "HTTP/1.1 100 Continue\r\n\r\n", 25);
+            });
+            if (rc == Recv::Closed) break;
+            if (rc == Recv::TooLarge) { respond(c, 413, "Payload Too Large", "{\"error\":\"body too large\"}", false); break; }
+            if (rc == Recv::Bad) { respond(c, 400, "Bad Request", "{\"error\":\"malformed request\"}", false); break; }
+            // request line: METHOD SP target SP HTTP/1.x
+            const size_t s1 = m.start.find(' '), s2 = m.start.rfind(' ');
+            if (s1 == std::string::npos || s2 == s1 || m.start.compare(s2 + 1, 7, "HTTP/1.") != 0) {
+                respond(c, 400, "Bad Request", "{\"error\":\"malformed request line\"}", false);
+                break;
+            }
+            const std::string method = m.start.substr(0, s1);
+            std::string target = m.start.substr(s1 + 1, s2 - s1 - 1);
+            const size_t q = target.find('?');
+            if (q != std::string::npos) target.erase(q);
+            const std::string *conn = header(m, "connection");
+            const bool keep = !(conn && lower(*conn) == "close") && m.start.compare(s2 + 1, 8, "HTTP/1.0") != 0;
+            ++served;
+            if (method != "GET" && method != "POST") { respond(c, 405, "Method Not Allowed", "{\"error\":\"GET or POST\"}", keep); continue; }
+            const std::string route = target.empty() || target[0] != '/' ? target : target.substr(1);
+            try {
+                respond(c, 200, "OK", m_Handler(method, route, m.body), keep);
+            } catch (const std::out_of_range &e) {
+                // wire::handle signals an unknown route this way; a missing JSON key inside a known route is the
+                // client's malformed body -- Drogon would answer 500 for the escaping exception either way
+                const bool unknown = std::string(e.what()).rfind("no such route", 0) == 0;
+                respond(c, unknown ? 404 : 500, unknown ? "Not Found" : "Internal Server Error", std::string("{\"error\":\"") + (unknown ? "unknown route" : "bad request body") + "\"}", keep);
+            } catch (const std::exception &) {
+                respond(c, 500, "Internal Server Error", "{\"error\":\"handler failed\"}", keep);
+            }
+            if (!keep) break;
+        }
+        ::close(c);
+    }
+    return served;
+}
+
+HttpTransport::HttpTransport(const std::string &host, uint16_t port) : m_Host(host), m_Port(port) {}
+HttpTransport::~HttpTransport() { if (m_Fd >= 0) ::close(m_Fd); }
+
+std::string HttpTransport::get(const std::string &route) { return request("GET", route, std::string()); }
+std::string HttpTransport::post(const std::string &route, const std::string &body) { return request("POST", route, body); }
+
+std::string HttpTransport::request(const char *method, const std::string &route, const std::string &body) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (m_Fd < 0) {
+            addrinfo hints{}, *res = nullptr;
+            hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+            if (::getaddrinfo(m_Host.c_str(), std::to_string(m_Port).c_str(), &hints, &res) != 0 || !res) throw std::runtime_error("HttpTransport: cannot resolve " + m_Host);
+            m_Fd = ::socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+            const bool ok = m_Fd >= 0 && ::connect(m_Fd, res->ai_addr, res->ai_addrlen) == 0;
+            ::freeaddrinfo(res);
+            if (!ok) { if (m_Fd >= 0) ::close(m_Fd); m_Fd = -1; throw std::runtime_error("HttpTransport: cannot connect to " + m_Host + ":" + std::to_string(m_Port)); }
+            int one = 1;
+            ::setsockopt(m_Fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        }
+        std::string head = std::string(method) + " /" + route + " HTTP/1.1\r\nHost: " + m_Host + ":" + std::to_string(m_Port) +
+                           "\r\nAccept: */*\r\nConnection: keep-alive\r\n";
+        if (std::strcmp(method, "POST") == 0) head += "Content-Type: application/json\r\nContent-Length: " + std::to_string(body.size()) + "\r\n";
+        head += "\r\n";
+        Message m;
+        std::string buf;
+        if (send_all(m_Fd, head.data(), head.size()) && send_all(m_Fd, body.data(), body.size()) &&
+            read_message(m_Fd, buf, m, (size_t)1 << 34, nullptr) == Recv::Ok) {
+            last_status = m.start.size() >= 12 ? std::atoi(m.start.c_str() + 9) : 0;
+            bytes_sent += body.size(); bytes_received += m.body.size();
+            const std::string *conn = header(m, "connection");
+            if (conn && lower(*conn) == "close") { ::close(m_Fd); m_Fd = -1; }
+            if (last_status != 200) throw std::runtime_error("HttpTransport: " + std::string(method) + " /" + route + " answered " + m.start);
+            return std::move(m.body);
+        }
+        ::close(m_Fd); m_Fd = -1;                                    // a keep-alive connection the server has closed: once more on a fresh one
+    }
+    throw std::runtime_error("HttpTransport: no answer from " + m_Host + ":" + std::to_string(m_Port));
+}
+
+}  // namespace wire

@@ -15,6 +15,8 @@
 #include <string>
 
 #include "../../include/prefhetch_hip.h"
+#include "../../include/server/http.h"
+#include <cstdlib>
 
 #ifdef PREFHETCH_WITH_DROGON
 #include <drogon/drogon.h>
@@ -263,14 +265,14 @@ void Server::export_index(std::vector<float> &centroids, std::vector<float> &cod
         check(pf_ivfpq_get_list(im.ivfpq, static_cast<uint32_t>(l), codes.data() + list_offsets[l] * kM, ids.data() + list_offsets[l]), "pf_ivfpq_get_list");
 }
 
+// Reference: drogon::app().addListener(SERVER_ADDRESS, SERVER_PORT); run() (/root/reference/src/server/server_lib.cpp:48-53).
+// Here the four routes (and the encrypted one) are served by the POSIX-socket listener of include/server/http.h; blocks
+// for the life of the process like Drogon's run().  PREFHETCH_LISTEN_PORT overrides the port.
 void Server::run_webserver() {
-#ifdef PREFHETCH_WITH_DROGON
-    drogon::app().addListener(kListenAddress, kListenPort);
-    drogon::app().run();
-#else
-    (void)kListenAddress; (void)kListenPort;
-    throw std::runtime_error("Server::run_webserver: built without Drogon (-DPREFHETCH_WITH_DROGON)");
-#endif
+    int port = kListenPort;
+    if (const char *e = std::getenv("PREFHETCH_LISTEN_PORT")) port = std::atoi(e);
+    wire::HttpListener listener(*this, kListenAddress, static_cast<uint16_t>(port));
+    listener.serve();
 }
 
 void Server::retrieve_centroids(std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> &centroids) const {

@@ -12,7 +12,9 @@
 #include <type_traits>
 
 #include "../../include/server/server_lib.h"
+#include "../../include/server/http.h"
 #include "../../include/server/wire.h"
+#include <thread>
 #include "../../include/client/client_lib.h"
 
 // ---- signature pins (reference include/server/server_lib.h:19-49) ----
@@ -302,6 +304,40 @@ int main(int argc, char **argv) {
             try { link.post("coarsesearch", "{\"preciseQuery\": [[1,2]]}"); } catch (const std::out_of_range &) { threw = true; }
             EXPECT(threw);
             set_transport(nullptr);
+
+            // ---- and over HTTP: the POSIX-socket listener (include/server/http.h) on an ephemeral port in a thread, the
+            // client library through HttpTransport -- what an unmodified reference client does against Drogon.  Results
+            // must equal the in-process run bit for bit.
+            {
+                wire::HttpListener listener(*srv, "127.0.0.1", 0);
+                std::thread th([&] { listener.serve(); });
+                {
+                    wire::HttpTransport web("127.0.0.1", listener.port());
+                    set_transport(&web);
+                    ping_server();
+                    std::vector<std::array<float, PRECISE_VECTOR_DIMENSIONS>> h_cents;
+                    get_centroids(h_cents);
+                    EXPECT(h_cents.size() == cents.size() && std::memcmp(h_cents.data(), cents.data(), cents.size() * sizeof cents[0]) == 0);
+                    std::vector<float> h_cs; std::vector<faiss_idx_t> h_ci; std::array<size_t, NQUERY> h_sz{};
+                    get_coarse_scores(c_near, q2, h_cs, h_ci, h_sz);
+                    EXPECT(h_sz == sz && h_ci == ci && h_cs.size() == cs.size() && std::memcmp(h_cs.data(), cs.data(), cs.size() * 4) == 0);
+                    std::array<std::array<float, COARSE_PROBE>, NQUERY> h_pd;
+                    get_precise_scores(c_coarse, q2, h_pd);
+                    EXPECT(std::memcmp(h_pd.data(), c_pd.data(), sizeof c_pd) == 0);
+                    auto h_rows = std::make_unique<std::array<std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, K>, NQUERY>>();
+                    std::array<std::array<faiss_idx_t, K>, NQUERY> h_ids;
+                    get_precise_vectors_pir(*c_best, *h_rows, h_ids);
+                    EXPECT(h_ids == c_ids && std::memcmp(h_rows->data(), c_rows->data(), sizeof *c_rows) == 0);
+                    bool refused = false;                                       // a malformed body: 500, as under Drogon
+                    try { web.post("coarsesearch", "{\"preciseQuery\": [[1,2]]}"); } catch (const std::runtime_error &) { refused = web.last_status == 500; }
+                    EXPECT(refused);
+                    std::printf("client library over HTTP/1.1 (127.0.0.1:%u): identical results; %zu request bytes, %zu response bytes\n",
+                                (unsigned)listener.port(), web.bytes_sent, web.bytes_received);
+                    set_transport(nullptr);
+                }
+                listener.stop();
+                th.join();
+            }
         }
     }
 

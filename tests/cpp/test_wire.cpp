@@ -10,6 +10,7 @@
 #include <string>
 
 #include "client_lib.h"
+#include "http.h"
 #include "wire.h"
 
 static int failures = 0;
@@ -140,9 +141,55 @@ static int recall(const char *path) {
     return 0;
 }
 
+// HTTP listener without a Server behind it: prints "PORT <n>", answers `n_requests` requests, exits.  Routes: GET /query
+// -> a tiny centroid array; POST /echo -> the request body; POST /boom -> the handler throws (500); POST /badbody -> a
+// std::out_of_range that is not a routing failure (500); anything else -> "no such route" (404).
+static int http(size_t n_requests) {
+    wire::HttpListener listener([](const std::string &method, const std::string &route, const std::string &body) -> std::string {
+        if (route == "query" && method == "GET") return "[[1.5,2.0]]";
+        if (route == "echo") return body;
+        if (route == "boom") throw std::runtime_error("boom");
+        if (route == "badbody") throw std::out_of_range("key 'preciseQuery' not found");
+        throw std::out_of_range("no such route: " + route);
+    }, "127.0.0.1", 0, 8u << 20);
+    std::printf("PORT %u\n", (unsigned)listener.port());
+    std::fflush(stdout);
+    const size_t served = listener.serve(n_requests);
+    std::printf("served %zu\n", served);
+    return 0;
+}
+
+// the C++ client against the same listener (in-process thread): keep-alive reuse, statuses, a 3 MB body
+#include <thread>
+static int http_loopback() {
+    wire::HttpListener listener([](const std::string &, const std::string &route, const std::string &body) -> std::string {
+        if (route == "echo") return body;
+        if (route == "query") return "[]";
+        throw std::out_of_range("no such route: " + route);
+    }, "127.0.0.1", 0);
+    std::thread th([&] { listener.serve(); });
+    {
+        wire::HttpTransport t("127.0.0.1", listener.port());
+        EXPECT(t.get("query") == "[]" && t.last_status == 200);
+        std::string big(3u << 20, 'x');
+        for (size_t i = 0; i < big.size(); i += 4097) big[i] = (char)('a' + i % 26);
+        EXPECT(t.post("echo", big) == big);
+        EXPECT(t.post("echo", "") == "");
+        EXPECT(throws<std::runtime_error>([&] { t.post("nowhere", "{}"); }) && t.last_status == 404);
+        EXPECT(t.post("echo", "{\"a\":1}") == "{\"a\":1}");          // the connection survived the 404
+        EXPECT(t.bytes_sent == big.size() + 9 && t.bytes_received >= big.size());
+    }
+    listener.stop();
+    th.join();
+    std::printf(failures ? "http loopback: %d FAILURES\n" : "http loopback: ok\n", failures);
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && std::strcmp(argv[1], "selftest") == 0) return selftest();
+    if (argc >= 3 && std::strcmp(argv[1], "http") == 0) return http((size_t)std::atoll(argv[2]));
+    if (argc >= 2 && std::strcmp(argv[1], "http-loopback") == 0) return http_loopback();
     if (argc >= 3 && std::strcmp(argv[1], "recall") == 0) return recall(argv[2]);
-    std::printf("usage: test_wire selftest | recall <file>\n");
+    std::printf("usage: test_wire selftest | recall <file> | http <n requests> | http-loopback\n");
     return 2;
 }

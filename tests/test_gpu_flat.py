@@ -155,6 +155,31 @@ def test_config3_prefilter_full_size(pf):
 
 
 @pytest.mark.parametrize("d,M,nlist,n,nq,nprobe", [(128, 32, 256, 10000, 5, 20), (64, 8, 16, 3000, 9, 3), (24, 6, 7, 500, 4, 7)])
+def test_config3_prefilter_full_size_gaussian(pf):
+    """BASELINE config 3 pre-filter on N(0,1) data (SURVEY 8(d)'s second law; the fp32-operand path): 1M x 128 base, 1024
+    queries, k = 200.  A 16-query slice against float64 distances: every returned distance within the north-star's 1e-5
+    relative tolerance of the exact one, every returned id a true top-k member within that tolerance (tie-tolerant), ids
+    unique, distances ascending; for all queries: ascending and equal to the gathered recomputation within tolerance."""
+    g = torch.Generator(device=_dev()).manual_seed(20250801 + 3)
+    nb, nq, k = 1_000_000, 1024, 200
+    xb = torch.randn((nb, 128), generator=g, device=_dev())
+    xq = torch.randn((nq, 128), generator=g, device=_dev())
+    idx = pf.FlatL2(xb, _dev())
+    assert not idx.exact16()                                 # Gaussian data never qualifies for 16-bit operands
+    D, I = idx.search(xq, k)
+    assert bool((D[:, 1:] >= D[:, :-1]).all())
+    assert torch.allclose(idx.l2_gathered(xq, I), D, rtol=RTOL, atol=0)
+    xb_h = xb.cpu().numpy().astype(np.float64)
+    for i in range(700, 716):
+        q = xq[i].cpu().numpy().astype(np.float64)
+        exact = ((xb_h - q) ** 2).sum(-1)
+        ids = I[i].cpu().numpy()
+        assert len(set(ids)) == k
+        assert np.allclose(D[i].cpu().numpy(), exact[ids], rtol=RTOL, atol=0)
+        kth = np.partition(exact, k - 1)[k - 1]
+        assert (exact[ids] <= kth * (1 + 4 * RTOL)).all()
+
+
 def test_ivfpq_search_lists_bit_exact(pf, d, M, nlist, n, nq, nprobe):
     """IndexIVFPQ::search_encrypted semantics (Server::coarseSearch, server_lib.cpp:111-138): ADC over the GIVEN lists,
     all stored vectors, unsorted, bit-exact against the oracle on the same index content (reference shapes first)."""

@@ -250,6 +250,29 @@ def test_config5_key_switch_full_ring(pf):
     assert (pf.to_host_u64(big_c) == np.repeat(exp, 20, axis=0)).all()
 
 
+def test_config5_key_switch_batch_256(pf):
+    """BASELINE config 5 at its batch size: 256 switched polynomials in one call (16 workspace rounds); rows 0, 17 and 255 are
+    independent random ciphertexts checked against the oracle, the rest repeat row 0 and must equal its result."""
+    N, qs = 32768, oracle.BFV_DEFAULT[32768]
+    D, B = 15, 256
+    rng = np.random.default_rng(20250801 + 55)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+    t3 = np.stack([rng.integers(0, q, (3, N), dtype=np.uint64) for q in qs[:D]], axis=1)
+    c3 = np.stack([rng.integers(0, q, (3, 2, N), dtype=np.uint64) for q in qs[:D]], axis=2)
+    exp3 = o.key_switch(t3, ksk, c3)
+    rows = {0: 0, 17: 1, 255: 2}
+    sel = np.array([rows.get(b, 0) for b in range(B)])
+    d_t = pf.to_device_u64(t3, _dev())[torch.from_numpy(sel).to(_dev())].contiguous()
+    d_c = pf.to_device_u64(c3, _dev())[torch.from_numpy(sel).to(_dev())].contiguous()
+    c.key_switch_(d_t, pf.to_device_u64(ksk, _dev()), d_c)
+    got = pf.to_host_u64(d_c)
+    for b in (0, 17, 255, 1, 16, 128, 254):
+        assert (got[b] == exp3[sel[b]]).all(), b
+    assert (got[sel == 0] == exp3[0]).all()
+
+
 def test_errors_are_statuses(pf):
     c = _ctx(pf, 1024, oracle.BFV_DEFAULT[1024])
     with pytest.raises(pf.PfError):

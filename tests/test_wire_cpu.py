@@ -77,3 +77,58 @@ def test_recall_rejects_short_ground_truth(tmp_path):
         f.write(np.zeros((NQUERY, 50), dtype=np.int32).tobytes())
     r = subprocess.run([BIN, "recall", str(path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "K greater than nearest neigbours" in r.stdout
+
+
+def test_http_transport_loopback_cpp_client():
+    r = subprocess.run([BIN, "http-loopback"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "http loopback: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_http_listener_serves_a_stock_http_client():
+    """the POSIX-socket listener (include/server/http.h) against Python's http.client, the way libcurl / cpr talks to the
+    reference's Drogon server: GET /query, POST bodies of the reference's shape (Query.cc:29-63), keep-alive, Expect:
+    100-continue, unknown route -> 404, handler exception -> 500, bad method -> 405"""
+    import http.client
+    import json
+    n = 9
+    p = subprocess.Popen([BIN, "http", str(n)], stdout=subprocess.PIPE, text=True)
+    try:
+        port = int(p.stdout.readline().split()[1])
+        c = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
+        c.request("GET", "/query")
+        r = c.getresponse()
+        assert r.status == 200 and r.getheader("Content-Type") == "application/json" and json.loads(r.read()) == [[1.5, 2.0]]
+        body = json.dumps({"preciseQuery": [[float(i % 7) for i in range(128)] for _ in range(5)],
+                           "nearestCentroidIndexes": [[i for i in range(20)] for _ in range(5)]})
+        c.request("POST", "/echo", body=body, headers={"Content-Type": "application/json"})       # same connection: keep-alive
+        r = c.getresponse()
+        assert r.status == 200 and r.read().decode() == body
+        big = "x" * (2 << 20)
+        c.request("POST", "/echo", body=big, headers={"Expect": "100-continue"})                   # what libcurl sends above 1 KB
+        r = c.getresponse()
+        assert r.status == 200 and r.read().decode() == big
+        for route, status in (("/nowhere", 404), ("/boom", 500), ("/badbody", 500)):
+            c.request("POST", route, body="{}")
+            r = c.getresponse()
+            assert r.status == status, (route, r.status)
+            r.read()
+        c.request("DELETE", "/query")
+        r = c.getresponse()
+        assert r.status == 405
+        r.read()
+        c.request("GET", "/query?x=1")                                                             # query strings are ignored
+        r = c.getresponse()
+        assert r.status == 200
+        r.read()
+        c2 = http.client.HTTPConnection("127.0.0.1", port, timeout=30)                            # a second connection once the first closes
+        c.close()
+        c2.request("GET", "/query", headers={"Connection": "close"})
+        r = c2.getresponse()
+        assert r.status == 200 and r.getheader("Connection") == "close"
+        r.read()
+        c2.close()
+        out, _ = p.communicate(timeout=30)
+        assert f"served {n}" in out
+    finally:
+        if p.poll() is None:
+            p.kill()
