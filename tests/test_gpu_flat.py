@@ -154,7 +154,6 @@ def test_config3_prefilter_full_size(pf):
     assert (I[500:516].cpu().numpy() == Ir).all() and (D[500:516].cpu().numpy() == Dr).all()
 
 
-@pytest.mark.parametrize("d,M,nlist,n,nq,nprobe", [(128, 32, 256, 10000, 5, 20), (64, 8, 16, 3000, 9, 3), (24, 6, 7, 500, 4, 7)])
 def test_config3_prefilter_full_size_gaussian(pf):
     """BASELINE config 3 pre-filter on N(0,1) data (SURVEY 8(d)'s second law; the fp32-operand path): 1M x 128 base, 1024
     queries, k = 200.  A 16-query slice against float64 distances: every returned distance within the north-star's 1e-5
@@ -180,6 +179,7 @@ def test_config3_prefilter_full_size_gaussian(pf):
         assert (exact[ids] <= kth * (1 + 4 * RTOL)).all()
 
 
+@pytest.mark.parametrize("d,M,nlist,n,nq,nprobe", [(128, 32, 256, 10000, 5, 20), (64, 8, 16, 3000, 9, 3), (24, 6, 7, 500, 4, 7)])
 def test_ivfpq_search_lists_bit_exact(pf, d, M, nlist, n, nq, nprobe):
     """IndexIVFPQ::search_encrypted semantics (Server::coarseSearch, server_lib.cpp:111-138): ADC over the GIVEN lists,
     all stored vectors, unsorted, bit-exact against the oracle on the same index content (reference shapes first)."""
