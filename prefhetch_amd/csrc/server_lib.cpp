@@ -43,7 +43,7 @@ struct DevBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
     void reserve(int dev, size_t n) {
-        if (n <= bytes) return;
+        if (ptr && dev == device && n <= bytes) return;           // a buffer of another device is never reused
         release();
         check(pf_malloc(dev, &ptr, n), "pf_malloc");
         device = dev; bytes = n;
@@ -133,6 +133,7 @@ struct Server::Impl {
         if (ivfpq) pf_ivfpq_destroy(ivfpq);
         if (ring) pf_ctx_destroy(ring);
         base = nullptr; centroids = nullptr; ivfpq = nullptr; ring = nullptr;
+        d_query.release(); d_ids.release(); d_out.release(); d_out2.release(); d_pt.release();   // they belong to the old device
     }
     // installs trained tables and creates the device objects
     void install(int dev, const float *base_rows, size_t n_base, std::vector<float> cent, std::vector<float> books) {
@@ -235,6 +236,8 @@ void Server::init_index() {
     f.read(magic, 8); f.read(reinterpret_cast<char *>(hdr), sizeof hdr);
     if (!f || std::memcmp(magic, kMagic, 8) != 0 || hdr[0] != static_cast<uint64_t>(NLIST) * kD || hdr[1] != static_cast<uint64_t>(kM) * kKsub * kDsub)
         throw std::runtime_error("Loaded index is not of type IndexIVFPQ");       // the reference's message for an unusable cache
+    // the file is not trusted: the vector count sizes two allocations and the list offsets index into them
+    if (hdr[2] > nb) throw std::runtime_error("Loaded index is not of type IndexIVFPQ");       // more stored vectors than base rows
     std::vector<float> cent(hdr[0]), books(hdr[1]);
     std::vector<uint64_t> off(NLIST + 1); std::vector<int64_t> ids(hdr[2]); std::vector<uint8_t> codes(hdr[2] * kM);
     f.read(reinterpret_cast<char *>(cent.data()), cent.size() * 4);
@@ -243,6 +246,10 @@ void Server::init_index() {
     f.read(reinterpret_cast<char *>(ids.data()), ids.size() * 8);
     f.read(reinterpret_cast<char *>(codes.data()), codes.size());
     if (!f) throw std::runtime_error("index cache is truncated");
+    bool sane = off[0] == 0 && off[NLIST] == hdr[2];
+    for (size_t l = 0; sane && l < static_cast<size_t>(NLIST); ++l) sane = off[l] <= off[l + 1];
+    for (size_t i = 0; sane && i < ids.size(); ++i) sane = ids[i] >= 0 && static_cast<uint64_t>(ids[i]) < nb;
+    if (!sane) throw std::runtime_error("Loaded index is not of type IndexIVFPQ");       // inconsistent offsets or labels outside the base
     std::lock_guard<std::mutex> g(m_Impl->lock);
     m_Impl->install(0, base.data(), nb, std::move(cent), std::move(books));
     std::vector<int64_t> list(ids.size());
