@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the round's measurement artefacts in ONE lease: bench line, rocprofv3 kernel stats of the same command, PMC passes
+# of the roofline kernel (stall breakdown, clock, HBM traffic), shape sweeps.  usage (GPU box): tools/prof_round.sh <tag>
+tag=$1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+python3 $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/prof_${tag}_bench.log 2>&1
+cd $R
+python3 tools/prof_summary.py $(find $O/prof_${tag}_bench -name "*kernel_stats.csv" | head -1) $O/${tag}_bench_kernel_stats.txt
+for pass in "a:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+            "b:SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" \
+            "c:GRBM_GUI_ACTIVE" "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+  bash tools/pmc_pass.sh ${tag}_ctpt_${pass%%:*} "${pass#*:}" ctpt 30 1024 > $O/${tag}_pmc_ctpt_${pass%%:*}.txt 2>&1
+done
+python3 tools/sweep_shapes.py > $O/${tag}_shapes_sweep.json 2> $O/${tag}_shapes_sweep.err
+python3 tools/sweep_flat.py > $O/${tag}_flat_sweep.json 2> $O/${tag}_flat_sweep.err
+python3 tools/time_ivfpq.py > $O/${tag}_ivfpq.json 2> $O/${tag}_ivfpq.err
+cd /tmp && PF_CONFIG=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_ks -- python3 $R/tools/run_kernel.py keyswitch 2 256 > $O/${tag}_keyswitch.txt 2>&1
+cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_ks -name "*kernel_stats.csv" | head -1) $O/${tag}_keyswitch_kernel_stats.txt
+tail -3 $O/${tag}_keyswitch.txt
+cat $O/${tag}_bench.json | head -c 600; echo
