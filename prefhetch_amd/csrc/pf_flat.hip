@@ -503,14 +503,14 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 // runs full.  A survivor that finds the list full (dense early chunks) is appended in global memory on the spot.
 struct Pend16 {
     static constexpr uint32_t CAP = 704;      // 2 x 34 KiB of operands + 1 KiB of rows + this list fit twice into a CU's 160 KiB
-    uint64_t key[CAP];
+    uint64_t key[CAP];                 // accumulator bits << 32 | base row id; flush() turns it into the (distance, id) key
     uint32_t loc[CAP];                 // local row; flush() adds the row-local index in the upper half
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
 };
 
 template <class GEO>
-__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, size_t q0, int tid) {
+__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid) {
     __syncthreads();                                              // every append has landed
     const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;   // adds beyond the capacity went to global memory directly
     if (n == 0) return;                                           // workgroup-uniform
@@ -527,7 +527,12 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, size
     __syncthreads();
     for (uint32_t e = tid; e < n; e += GEO::THREADS) {
         const uint32_t loc = pd.loc[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
-        if (pos < p.cap) p.cand[(q0 + row) * p.cap + pos] = pd.key[e];
+        if (pos < p.cap) {                                       // the distance is formed here, once per survivor, not in the tile sweep
+            const uint64_t raw = pd.key[e];
+            const uint32_t id = (uint32_t)raw;
+            const float dist = fmaf(-2.f, __uint_as_float((uint32_t)(raw >> 32)), sA[2 * row] + p.bn[id]);
+            p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+        }
     }
     __syncthreads();
     if (tid == 0) pd.n = 0;
@@ -561,18 +566,19 @@ __device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&a
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) { pass[jj] = acc[i][jj][r] >= rqs[e] + bnh[jj]; any |= __ballot(pass[jj]); }
                 if (any == 0) continue;                                  // wave-uniform, and the common case in late chunks
+                // 32 x 2 copies of this block make up most of the kernel's code: it only parks (accumulator, id); distance and key
+                // are formed by flush().  The overflow branch is laid out away from the sweep.
                 const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float qn = sA[2 * lrow];
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
                     if (!pass[jj]) continue;
-                    const float dist = fmaf(-2.f, acc[i][jj][r], qn + bnv[jj]);      // exact data: dist <= tau is the verdict above
-                    const uint64_t key = make_key(dist < 0.f ? 0.f : dist, (uint32_t)(p.nb_first + col[jj]));
+                    const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
                     const uint32_t e2 = atomicAdd(&pd.n, 1u);
-                    if (e2 < Pend16::CAP) { pd.key[e2] = key; pd.loc[e2] = (uint32_t)lrow; }
+                    if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.key[e2] = ((uint64_t)__float_as_uint(acc[i][jj][r]) << 32) | id; pd.loc[e2] = (uint32_t)lrow; }
                     else {                                               // list full: straight to the candidate list
+                        const float dist = fmaf(-2.f, acc[i][jj][r], sA[2 * lrow] + bnv[jj]);
                         const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
-                        if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = key;
+                        if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
                     }
                 }
             }
@@ -718,13 +724,13 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         if constexpr (FILTER) {
             l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, bnv);
             __syncthreads();                                        // the tile's one barrier: the other buffer is complete, the list settled
-            if (pend.n > Pend16::CAP / 2) pend16_flush<GEO>(p, pend, q0, tid);   // workgroup-uniform
+            if (pend.n > Pend16::CAP / 2) pend16_flush<GEO>(p, pend, stage, q0, tid);   // workgroup-uniform
         } else {
             l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
             __syncthreads();
         }
     }
-    if constexpr (FILTER) pend16_flush<GEO>(p, pend, q0, tid);
+    if constexpr (FILTER) pend16_flush<GEO>(p, pend, stage, q0, tid);
 }
 
 // ---- selection -----------------------------------------------------------------------------------
