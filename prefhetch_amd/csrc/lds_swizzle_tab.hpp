@@ -30,7 +30,7 @@ constexpr SwzEntry SWZ_TABLE[] = {
     PF_SWZ(14, 4, 2, 4, 1, 1,  2, 2, 0,  6, 3, 2)
     PF_SWZ(14, 5, 0, 9, 1, 4,  0, 0, 0,  0, 0, 0)
     PF_SWZ(14, 5, 1, 4, 1, 3,  5, 5, 0,  0, 0, 0)
-    PF_SWZ(15, 5, 0, 0, 0, 0,  0, 0, 0,  0, 0, 0)
+    PF_SWZ(15, 5, 0, 10, 1, 4,  0, 0, 0,  0, 0, 0)
     PF_SWZ(15, 6, 0, 9, 2, 3,  0, 0, 0,  0, 0, 0)
     PF_SWZ(15, 6, 1, 4, 2, 1,  6, 5, 0,  0, 0, 0)
     PF_SWZ(15, 5, 1, 5, 1, 3,  6, 5, 0,  0, 0, 0)

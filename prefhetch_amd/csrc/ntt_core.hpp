@@ -186,8 +186,16 @@ template <int LOGN_>
 struct Geo {
     static constexpr int LOGN = LOGN_;
     static constexpr int N = 1 << LOGN;
-    // N = 32768: 64 coefficients per thread, 512 threads -- 2 waves per SIMD leave the 64-bit butterflies 256 VGPRs
-    static constexpr int LOGR = LOGN >= 15 ? 6 : (LOGN >= 12 ? PF_LOGR_LARGE : 4);
+    // N = 32768: 64 coefficients per thread, 512 threads -- 2 waves per SIMD leave the 64-bit butterflies 256 VGPRs.
+    // PF_LOGR_15 = 5 selects 1024 threads x 32 instead (three passes of five stages, four waves per SIMD inside the one
+    // workgroup a CU holds, 128 registers): built, verified on the host simulator and on the GPU, and measured in round 2 --
+    // forward 1.90 vs 1.95 ms, inverse 2.30 vs 1.99 ms, ct x pt 3.88 vs 3.67 ms, key switch 25.9 vs 26.6 ms per 256: no win.
+    // The lone workgroup's phases (global load, passes, exchanges, store) do not overlap whatever its wave count, and the
+    // last-pass layout then reads 256-byte runs per lane.  Kept selectable; the default stays 64.
+#ifndef PF_LOGR_15
+#define PF_LOGR_15 6
+#endif
+    static constexpr int LOGR = LOGN >= 15 ? PF_LOGR_15 : (LOGN >= 12 ? PF_LOGR_LARGE : 4);
     static constexpr int R = 1 << LOGR;
     static constexpr int T = N / R;                               // threads per workgroup
     static constexpr int P = (LOGN + LOGR - 1) / LOGR;            // passes per transform
@@ -207,7 +215,37 @@ struct Geo {
     // two-round half-buffer exchange below relies on) while lanes 0..2^y-1 still cover one contiguous run.
     static constexpr int TB = LOGN - LOGR;                        // thread-id bits
     static constexpr int YBIT = P >= 2 ? a(P - 2 < 0 ? 0 : P - 2) + LOGR - 1 : 0;
+    // index bit of the top REGISTER bit (k >= R/2) of layout p: the highest carried bit, or the highest transformed one
+    static constexpr int topreg(int p) { return (p == P - 1 && nh(p) > 0) ? LOGN - 1 : a(p) + nl(p) - 1; }
+    // thread-id bit that carries index bit b in layout p (the inverse of base(); b must be a thread bit there)
+    static constexpr int tidbit_of(int p, int b) {
+        if (NH0 && p == 1) return b == LOGN - 1 ? TB - 1 : b == a(1) - 1 ? TB - 2 : b < a(1) - 1 ? b : b - (a(1) + LOGR) + (a(1) - 1);
+        if (NH0 && p == 2) return b == LOGN - 1 ? TB - 1 : b == YBIT ? TB - 2 : b < YBIT ? b - nl(2) : b - nl(2) - 1;
+        if (p == P - 1 && P >= 2) {
+            const int NL = nl(P - 1), y = YBIT - NL, f = b - NL;
+            return f == y ? TB - 1 : (f < y ? f : f - 1);
+        }
+        return b < a(p) ? b : b - nl(p);
+    }
+    // NH0: three passes of LOGR stages each (N = 32768 at 32 coefficients per thread): the last pass carries no top bits, so
+    // the role-swapping bit pairs of the two exchanges are (LOGN-1, a(0)-1) and (a(0)-1, a(1)-1).  Every thread must take the
+    // same half as a writer and as a reader of an exchange (it overwrites the registers it has just written out), i.e. on
+    // both sides of an exchange the selector has to be the SAME wave-level thread-id bit: bit TB-1 carries index bit a(0)-1
+    // in layout 0 and LOGN-1 in layout 1 (first exchange), bit TB-2 carries a(1)-1 in layout 1 and a(0)-1 in layout 2.
+    static constexpr bool NH0 = P == 3 && nh(P - 1) == 0 && LOGN - LOGR >= 8;
     static PF_HD int base(int p, int tid) {
+        if constexpr (NH0) {
+            if (p == 1) {
+                constexpr int A1 = a(1);                             // thread bits: [0, A1-1) low, then the bits above pass 1's field
+                const int low = tid & ((1 << (A1 - 1)) - 1), mid = (tid >> (A1 - 1)) & ((1 << (TB - 2 - (A1 - 1))) - 1);
+                return low | (mid << (A1 + LOGR)) | (((tid >> (TB - 2)) & 1) << (A1 - 1)) | ((tid >> (TB - 1)) << (LOGN - 1));
+            }
+            if (p == 2) {
+                constexpr int NL = nl(2), y = YBIT - NL;             // lanes count runs in order: thread bits [0, y) sit right above the run
+                const int lo = tid & ((1 << (TB - 2)) - 1);
+                return ((lo & ((1 << y) - 1)) << NL) | (((tid >> (TB - 2)) & 1) << YBIT) | ((lo >> y) << (YBIT + 1)) | ((tid >> (TB - 1)) << (LOGN - 1));
+            }
+        }
         if (p == P - 1 && P >= 2) {
             constexpr int NL = nl(P - 1), y = YBIT - NL;
             const int msb = tid >> (TB - 1), lo = tid & ((1 << (TB - 1)) - 1);
@@ -726,9 +764,24 @@ struct Xchg {
     // branch, not a per-lane select.
     // Forced when N*8 bytes do not fit a CU's LDS at all (N = 32768).
     static constexpr bool FITS_WHOLE = G::N * 8 <= 128 * 1024;
-    static constexpr bool HALF = (!FITS_WHOLE || (PF_HALF_EXCHANGE && A::HALF_EXCHANGE_OK)) && G::P == 3 && G::nh(G::LAST) >= 1 && G::T >= 128;
+    static constexpr bool HALF = (!FITS_WHOLE || (PF_HALF_EXCHANGE && A::HALF_EXCHANGE_OK)) && G::P == 3 && G::T >= 128;
     static_assert(HALF || FITS_WHOLE, "this ring degree needs the half-buffer exchange");
     static constexpr int LDS_ENTRIES = HALF ? G::N / 2 : G::N;
+};
+
+// The two index bits that swap roles in exchange PAIR (layouts PAIR and PAIR + 1): X is the top register bit of layout PAIR,
+// Y the top register bit of layout PAIR + 1; each is a thread bit on the other side.  Seen over (X, Y) the exchange is a 2x2
+// block transpose.  A thread's half-selector is ITS index bit that is the other side's top register bit; in a round
+// exactly the elements with X != Y (round 0) or X == Y (round 1) are in flight, so ONE of the two bits can be dropped from
+// the LDS position: the top index bit where it takes part (every geometry whose last pass carries top bits), else X.
+// Geo::base places the thread-id bits so that both selectors of an exchange are the same wave-level thread-id bit.
+template <class G, int PAIR>
+struct XPair {
+    static constexpr int X = G::topreg(PAIR), Y = G::topreg(PAIR + 1);
+    static constexpr int DROP = (X == G::LOGN - 1 || Y == G::LOGN - 1) ? G::LOGN - 1 : X;
+    template <int SIDE> static constexpr int selbit() { return SIDE == PAIR ? Y : X; }
+    template <int SIDE> static constexpr int sel_tidbit() { return G::tidbit_of(SIDE, selbit<SIDE>()); }
+    static constexpr int compress(int v) { return (v & ((1 << DROP) - 1)) | ((v >> (DROP + 1)) << DROP); }
 };
 
 #if defined(__HIPCC__)
@@ -741,23 +794,25 @@ PF_HD int wave_uniform(int v) { return v; }
 // five bits, so for register k:  position = (slot(base) ^ c_k) + khi_k, with c_k < 32 a compile-time constant
 // taking few distinct values and khi_k the (compile-time) high part of koff -- i.e. a handful of base registers
 // plus the 16-bit immediate offset of ds_read/ds_write, instead of one XOR per access.
-template <class G, int PAIR, int SIDE, int MASK>
+template <class G, int PAIR, int SIDE, bool HALFBUF>
 struct XchgAddr {
     int v[32];                                 // slot(base) ^ c for every c; unused entries are dead code
+    static constexpr int pos(int s) { return HALFBUF ? XPair<G, PAIR>::compress(s) : s; }     // drops one index bit (above bit 4)
     PF_HD explicit XchgAddr(int tid) {
-        const int sb = G::template slot<PAIR>(G::base(SIDE, tid)) & MASK;
+        const int s0 = G::template slot<PAIR>(G::base(SIDE, tid));
+        const int sb = HALFBUF ? ((s0 & ((1 << XPair<G, PAIR>::DROP) - 1)) | ((s0 >> (XPair<G, PAIR>::DROP + 1)) << XPair<G, PAIR>::DROP)) : s0;
 #pragma unroll
         for (int c = 0; c < 32; ++c) v[c] = sb ^ c;
     }
     static constexpr int ck(int k) { return G::template slot<PAIR>(G::koff(SIDE, k) & 31) ^ (G::template slot<PAIR>(G::koff(SIDE, k) & ~31) & 31); }
-    static constexpr int khi(int k) { return G::koff(SIDE, k) & ~31 & MASK; }
+    static constexpr int khi(int k) { return pos(G::koff(SIDE, k) & ~31); }
     template <class V> PF_HD V *at(V *lds, int k) const { return lds + khi(k) + v[ck(k)]; }
 };
 
 // one round of the half-buffer exchange: every thread writes register half `sel` and reads the same half back
 template <class G, class A, int WR, int RD, class Sync>
-PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAddr<G, (WR < RD ? WR : RD), WR, G::N / 2 - 1> &aw,
-                      const XchgAddr<G, (WR < RD ? WR : RD), RD, G::N / 2 - 1> &ard, int sel, Sync &&sync) {
+PF_HD void half_round(typename A::V (&r)[G::R], typename A::V *lds, const XchgAddr<G, (WR < RD ? WR : RD), WR, true> &aw,
+                      const XchgAddr<G, (WR < RD ? WR : RD), RD, true> &ard, int sel, Sync &&sync) {
     constexpr int H = G::R / 2;
     PF_STAMP_X(0);
     sync();
@@ -795,8 +850,8 @@ PF_HD void exchange(typename A::V (&r)[G::R], typename A::V *lds, int tid, Sync 
     static_assert(WR - RD == 1 || RD - WR == 1, "exchanges join adjacent passes");
     constexpr int PAIR = WR < RD ? WR : RD;
     if constexpr (!Xchg<G, A>::HALF) {
-        const XchgAddr<G, PAIR, WR, G::N - 1> aw(tid);
-        const XchgAddr<G, PAIR, RD, G::N - 1> ard(tid);
+        const XchgAddr<G, PAIR, WR, false> aw(tid);
+        const XchgAddr<G, PAIR, RD, false> ard(tid);
         sync();                                   // previous readers of the buffer are done
 #pragma unroll
         for (int k = 0; k < G::R; ++k) *aw.at(lds, k) = r[k];
@@ -804,9 +859,15 @@ PF_HD void exchange(typename A::V (&r)[G::R], typename A::V *lds, int tid, Sync 
 #pragma unroll
         for (int k = 0; k < G::R; ++k) r[k] = *ard.at(lds, k);
     } else {
-        const XchgAddr<G, PAIR, WR, G::N / 2 - 1> aw(tid);       // LDS position = slot with the top index bit dropped
-        const XchgAddr<G, PAIR, RD, G::N / 2 - 1> ard(tid);
-        const int t = wave_uniform(tid >> (G::TB - 1));           // this thread's half (top thread-id bit)
+        using XP = XPair<G, PAIR>;
+        const XchgAddr<G, PAIR, WR, true> aw(tid);               // LDS position = slot with one of the two role-swapping bits dropped
+        const XchgAddr<G, PAIR, RD, true> ard(tid);
+        // This thread's half: as a writer its index bit Y (or X) in layout WR, as a reader its index bit X (or Y) in layout RD.
+        // Both must be the same thread-id bit -- a thread reads into the registers it has just written out -- and a
+        // wave-level one, so that the register half is chosen by a scalar branch.
+        static_assert(XP::template sel_tidbit<WR>() == XP::template sel_tidbit<RD>() && XP::template sel_tidbit<WR>() >= 6,
+                      "the layouts of this geometry do not line the half selectors up");
+        const int t = wave_uniform((tid >> XP::template sel_tidbit<WR>()) & 1);
         half_round<G, A, WR, RD>(r, lds, aw, ard, t ^ 1, sync);   // off-diagonal blocks
         half_round<G, A, WR, RD>(r, lds, aw, ard, t, sync);       // diagonal blocks
     }

@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) k_ks_mac(KsArgs p) {
     for (uint32_t jj = 0; jj < per_thread; ++jj) {
         const size_t n2 = ((size_t)ch << chunk_log) / 2 + jj * 256 + threadIdx.x;      // index of a coefficient PAIR
         uint64_t lo[2][2] = {{0, 0}, {0, 0}}, hi[2][2] = {{0, 0}, {0, 0}};            // [component][element]
+#pragma unroll 5                      // five digits' loads (15 x 16 bytes per lane) in flight: the kernel is bound by memory latency, not arithmetic
         for (uint32_t I = 0; I < p.D; ++I) {
             const ulonglong2 xv = reinterpret_cast<const ulonglong2 *>(p.x + ((b * p.D + I) * p.K + J) * N)[n2];
 #pragma unroll

@@ -19,15 +19,13 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "ntt_golden.npz"))
 
 
-@pytest.fixture(scope="session")
-def sim_lib():
-    """Host execution of the device NTT core (tests/cpp/sim_ntt.cpp), built on demand."""
+def _build_sim(name, extra):
     import ctypes as C
-    so = os.path.join(ROOT, "tests", "cpp", "libpf_sim.so")
+    so = os.path.join(ROOT, "tests", "cpp", name)
     src = os.path.join(ROOT, "tests", "cpp", "sim_ntt.cpp")
-    deps = [src] + [os.path.join(ROOT, "prefhetch_amd", "csrc", f) for f in ("ntt_core.hpp", "tables.hpp")]
+    deps = [src] + [os.path.join(ROOT, "prefhetch_amd", "csrc", f) for f in ("ntt_core.hpp", "tables.hpp", "lds_swizzle_tab.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-std=c++20", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-DPF_RANGE_CHECK", "-shared", "-fPIC", src, "-o", so])
+        subprocess.check_call(["g++", "-std=c++20", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-DPF_RANGE_CHECK", "-shared", "-fPIC"] + extra + [src, "-o", so])
     lib = C.CDLL(so)
     u64p = C.POINTER(C.c_uint64)
     lib.pf_sim_run.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
@@ -35,6 +33,18 @@ def sim_lib():
     lib.pf_sim_psi.restype = C.c_uint64
     lib.pf_sim_psi.argtypes = [C.c_int, C.c_uint64]
     return lib
+
+
+@pytest.fixture(scope="session")
+def sim_lib_1024x32():
+    """The same core with the selectable N = 32768 geometry of 1024 threads x 32 coefficients (-DPF_LOGR_15=5)."""
+    return _build_sim("libpf_sim_r5.so", ["-DPF_LOGR_15=5"])
+
+
+@pytest.fixture(scope="session")
+def sim_lib():
+    """Host execution of the device NTT core (tests/cpp/sim_ntt.cpp), built on demand."""
+    return _build_sim("libpf_sim.so", [])
 
 
 def edge_poly(rng, N, q, kind):

@@ -57,6 +57,34 @@ def test_device_core_on_host_simulator(sim_lib, logn, q, arith):
     assert sim_lib.pf_sim_range_violations() == 0           # the lazy butterflies stayed inside their analysed bounds
 
 
+@pytest.mark.parametrize("q,arith", [(0x7FFFFFFFE90001, 2), (0xFFFFFFFFF70001, 2), (0x7FFFFDB0001, 0), (0x1FFFFFFFFFE10001, 1)])
+def test_selectable_geometry_1024x32_at_n32768(sim_lib_1024x32, q, arith):
+    """N = 32768 as 1024 threads x 32 coefficients (three full passes; both half-exchange selectors on wave-level thread-id
+    bits, the dropped position bit in the middle of the index for the second exchange): forward, inverse and the fused
+    product against the oracle, on every arithmetic family"""
+    lib = sim_lib_1024x32
+    N = 32768
+    o = oracle.Oracle(N, [q])
+    rng = np.random.default_rng(q & 0xFFFF)
+    for kind in (0, 1):
+        a, b = edge_poly(rng, N, q, kind), edge_poly(rng, N, q, 0)
+        dst = np.empty(N, dtype=np.uint64)
+        assert lib.pf_sim_run(15, q, arith, 0, 0, _p(a), _p(a), _p(dst)) == 0
+        A = o.ntt_forward(a)
+        assert (dst == A).all()
+        assert lib.pf_sim_run(15, q, arith, 1, 0, _p(A), _p(A), _p(dst)) == 0
+        assert (dst == a).all()
+        bn = o.ntt_forward(b)
+        for flags in (0, 3, 5):
+            src = A if flags & 2 else a
+            acc0 = edge_poly(rng, N, q, 0)
+            dst = acc0.copy()
+            exp = o.ct_pt_mul(np.stack([src, src]).reshape(1, 2, 1, N), bn.reshape(1, 1, N), flags, acc=np.stack([acc0, acc0]).reshape(1, 2, 1, N)).reshape(2, N)[0]
+            assert lib.pf_sim_run(15, q, arith, 2, flags, _p(src), _p(bn), _p(dst)) == 0
+            assert (dst == exp).all(), flags
+    assert lib.pf_sim_range_violations() == 0
+
+
 def test_simulator_golden_n1024(sim_lib, golden):
     for ci in (4, 5):
         g = lambda k: golden[f"c{ci}_{k}"]
