@@ -1264,9 +1264,10 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
         if (b16) {
-            // column tiles per workgroup: as many as keep every workgroup slot of the device (2 per CU) busy, at most 8
+            // column tiles per workgroup: as many as keep every workgroup slot of the device (2 per CU) busy, at most 16
             size_t group = nct * t.n_qtiles / (2 * (size_t)f->num_cus * 2);
-            group = group < 1 ? 1 : group > 8 ? 8 : group;
+            static const size_t group_cap = getenv("PF_FLAT_GROUP_CAP") ? (size_t)atoi(getenv("PF_FLAT_GROUP_CAP")) : 8;   // experiments
+            group = group < 1 ? 1 : group > group_cap ? group_cap : group;
             const size_t n_groups = (nct + group - 1) / group;
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
