@@ -327,7 +327,8 @@ def main():
     extras = rank == 0 and world == 1 and not args.no_extras
     # sustained rate of the roofline kernel: back-to-back launches, nothing in between (device power management differs)
     sustained_ms = None
-    if rank == 0 and world == 1:
+    if extras:                                                   # (skipped with --no-extras, so that a rocprofv3 --stats run of the
+        # timed steps averages the interleaved launches only)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(10):
             ctx.ct_pt_mul(ct, pt, out=out)

@@ -149,6 +149,6 @@ def test_bench_single_process_group():
 
 def test_bench_default_line_is_unchanged_in_shape():
     r = _run_bench([], {})
-    assert r["n_gpus"] == 1 and r["verified"] is True and r["roofline"]["sustained_frac"] > 0
+    assert r["n_gpus"] == 1 and r["verified"] is True and r["roofline"]["frac"] > 0
     for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in r
