@@ -539,18 +539,38 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
     __syncthreads();
 }
 
+#ifdef PF_FLAT_STAMPS        // experiments (tools/flat_stamps.py): s_memtime at the phase boundaries of the tile walk
+#define PF_FS_WGS 32
+#define PF_FS_TILES 16
+#define PF_FS_K 8
+__device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF_FS_K];
+#define PF_FSTAMP(k) do { if (fs_on && (tid & 63) == 0 && ct - ct0 < PF_FS_TILES) \
+    pf_flat_stamp_buf[(((blockIdx.x - 2048) * 4 + (tid >> 6)) * PF_FS_TILES + (ct - ct0)) * PF_FS_K + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PF_FSTAMP(k) do { } while (0)
+#endif
 // FILTER epilogue of the bf16 tiles (EXACT thresholds, rows prestaged in `sA`: (norm, threshold) pairs and, at 3*TM, the
 // accumulator thresholds).  No barrier inside: the caller's per-tile barrier follows.
-template <class GEO>
+// Two parts.  (1) A branch-free sweep: accumulator >= threshold is the sign of their difference, shifted into one 32-bit
+// word per column block (v_sub_f32 + v_alignbit_b32 per value).  A verdict per row by ballot and scalar branch -- the
+// first version -- made every one of the 32 rows of a lane wait for a vector compare to reach the scalar unit: 3 650
+// cycles per tile in the phase stamps (tools/flat_stamps.py), half of the tile's period, with the vector pipe idle.
+// (2) The rows that hold a survivor anywhere in the wave (OR of the words over the lanes: six DPP steps) are visited by
+// scalar bit tests; a lane reserves room in the list for all its survivors of the tile with ONE returning LDS atomic.
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+template <class GEO, class Stamp = NoStamp>
 __device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&acc)[GEO::MI][GEO::NJ], const float *sA, Pend16 &pd, size_t q0,
-                                                   int wm, int tid, const size_t (&col)[GEO::NJ], const float (&bnv)[GEO::NJ]) {
+                                                   int wm, int tid, const size_t (&col)[GEO::NJ], const bool (&col_ok)[GEO::NJ],
+                                                   const float (&bnv)[GEO::NJ], Stamp stamp = Stamp{}) {
     constexpr int TM = GEO::TM, MI = GEO::MI, NJ = GEO::NJ;
+    static_assert(MI * 16 == 32, "one verdict word per column block: 32 accumulator rows per lane");
     int lane = tid & 63;
     asm volatile("" : "+v"(lane));       // opaque per call: or hipcc computes the 32 local-row numbers of this lane once, ahead of the
                                          // caller's tile loop, and keeps them in 32 registers across it (spills)
     float bnh[NJ];
+    uint32_t fail[NJ];
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) bnh[jj] = 0.5f * bnv[jj];            // NaN past the end of the chunk: compares false
+    for (int jj = 0; jj < NJ; ++jj) { bnh[jj] = col_ok[jj] ? 0.5f * bnv[jj] : 0.f; fail[jj] = 0; }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -559,28 +579,51 @@ __device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&a
 #pragma unroll
             for (int e = 0; e < 8; ++e) rqs[e] = sA[3 * TM + wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int r = r8 + e;
-                bool pass[NJ];
-                uint64_t any = 0;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) { pass[jj] = acc[i][jj][r] >= rqs[e] + bnh[jj]; any |= __ballot(pass[jj]); }
-                if (any == 0) continue;                                  // wave-uniform, and the common case in late chunks
-                // 32 x 2 copies of this block make up most of the kernel's code: it only parks (accumulator, id); distance and key
-                // are formed by flush().  The overflow branch is laid out away from the sweep.
-                const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int e = 0; e < 8; ++e)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
-                    if (!pass[jj]) continue;
-                    const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
-                    const uint32_t e2 = atomicAdd(&pd.n, 1u);
-                    if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.key[e2] = ((uint64_t)__float_as_uint(acc[i][jj][r]) << 32) | id; pd.loc[e2] = (uint32_t)lrow; }
-                    else {                                               // list full: straight to the candidate list
-                        const float dist = fmaf(-2.f, acc[i][jj][r], sA[2 * lrow] + bnv[jj]);
-                        const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
-                        if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
-                    }
+                    // acc >= t  <=>  the sign of fl(acc - t) is clear (t = +-inf included; t is never NaN: rows past nq carry
+                    // +inf, columns past the end of the chunk 0 and are masked below); row s = 16 i + r ends up in bit 31 - s
+                    const float dlt = acc[i][jj][r8 + e] - (rqs[e] + bnh[jj]);
+                    fail[jj] = __builtin_amdgcn_alignbit(fail[jj], __float_as_uint(dlt), 31);
                 }
+        }
+    }
+    uint32_t surv[NJ], mine = 0, cnt = 0;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) { surv[jj] = col_ok[jj] ? ~fail[jj] : 0u; mine |= surv[jj]; cnt += __popc(surv[jj]); }
+    stamp(4);
+    const uint32_t rows_hit = __reduce_or_sync(~0ull, mine);           // wave-uniform: bit 31 - s set = row s holds a survivor
+    if (rows_hit == 0) { stamp(5); return; }
+    uint32_t slot = cnt ? atomicAdd(&pd.n, cnt) : 0u;                   // this lane's survivors take slot, slot + 1, ...
+    stamp(5);
+    // one copy of the parking code: the accumulator row is picked by a wave-uniform register index (s_set_gpr_idx_on), not by
+    // 32 unrolled blocks -- rows with a survivor are few in the long late chunks, and a block per row was 30 KiB of code
+    // (the accumulators pass through an empty asm first: indexed straight out of the array `acc`, hipcc turns the read into a load
+    // from a computed address before it has unrolled the loops around the array, and the whole array then lives in scratch)
+    f32x16 av[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) { av[i][jj] = acc[i][jj]; asm volatile("" : "+v"(av[i][jj])); }
+    for (uint32_t h = rows_hit; h;) {
+        const int b = 31 - __builtin_clz(h);                            // scalar: row s = 31 - b
+        h &= ~(1u << b);
+        const int s = 31 - b, i = s >> 4, r = s & 15;
+        const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            float a_lo = av[0][jj][r], a_hi = av[MI - 1][jj][r];       // two indexed moves; the empty asm keeps hipcc from selecting between
+            asm volatile("" : "+v"(a_lo), "+v"(a_hi));                  // the two 16-register rows first (16 v_cndmask)
+            const float a = i ? a_hi : a_lo;
+            if (!((surv[jj] >> b) & 1u)) continue;
+            const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
+            const uint32_t e2 = slot++;
+            if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.key[e2] = ((uint64_t)__float_as_uint(a) << 32) | id; pd.loc[e2] = (uint32_t)lrow; }
+            else {                                               // list full: straight to the candidate list
+                const float dist = fmaf(-2.f, a, sA[2 * lrow] + bnv[jj]);
+                const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
+                if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
             }
         }
     }
@@ -664,7 +707,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             const size_t c = c0 + wn + 32 * jj + (lane & 31);
-            bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : (FILTER ? __builtin_nanf("") : 0.f);
+            bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
     auto commit_b = [&](char *buf) {
@@ -676,10 +719,15 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     commit_b(sB16_0);
     if (ct0 + 1 < ct1) fetch_b(ct0 + 1);
     __syncthreads();
+#ifdef PF_FLAT_STAMPS
+    const bool fs_on = FILTER && p.nb_count == 524288 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
+#endif
     for (uint32_t ct = ct0; ct < ct1; ++ct) {
         const uint32_t cur = (ct - ct0) & 1u;
+        PF_FSTAMP(0);
         // tile ct+1 goes into the other buffer: its last readers (tile ct-1) passed the barrier that ended that tile
         if (ct + 1 < ct1) commit_b(cur ? sB16_0 : sB16_1);
+        PF_FSTAMP(1);
         const size_t c0 = (size_t)ct * TN;
         size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
 #pragma unroll
@@ -701,6 +749,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         // itself hipcc hoists every fragment read of the tile to the top)
         const char *fb = (cur ? sB16_1 : sB16_0) + (wn + (lane & 31)) * PITCH + (lane >> 5) * 16;
         bf16x8 b[2][NJ];
+        PF_FSTAMP(2);
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) b[0][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH);
 #pragma unroll
@@ -721,9 +770,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         // the tile loop and keeps them alive across it
         size_t q0t = q0;
         asm volatile("" : "+s"(q0t));
+        PF_FSTAMP(3);
         if constexpr (FILTER) {
-            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, bnv);
+#ifdef PF_FLAT_STAMPS
+            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, bnv, [&](int k) { PF_FSTAMP(k); });
+#else
+            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, bnv);
+#endif
+            PF_FSTAMP(6);
             __syncthreads();                                        // the tile's one barrier: the other buffer is complete, the list settled
+            PF_FSTAMP(7);
             if (pend.n > Pend16::CAP / 2) pend16_flush<GEO>(p, pend, stage, q0, tid);   // workgroup-uniform
         } else {
             l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
@@ -1354,3 +1410,10 @@ pf_status pf_gather_rows(pf_flat *f, const int64_t *ids, size_t n_ids, float *ou
 }
 
 }  // extern "C"
+
+#ifdef PF_FLAT_STAMPS
+extern "C" int pf_flat_debug_stamps(unsigned long long *out, size_t n) {
+    const size_t have = sizeof(pf::pf_flat_stamp_buf) / 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::pf_flat_stamp_buf), (n < have ? n : have) * 8);
+}
+#endif
