@@ -71,28 +71,48 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
 // value (integer, |v| <= 256): the base when the index is created (the 16-bit image is dropped if a single value fails), the
 // queries at the start of every search (per 128-query tile; a tile with an inexact value runs the fp32 loop).  Nothing is
 // assumed about the data, and a search needs no host synchronisation to pick its path.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;      // 16 bytes in registers (HIP's uint4 struct in an array stays in scratch)
 constexpr float BF16_EXACT_MAX = 256.f;
 __device__ __forceinline__ bool bf16_exact(float v) { return v == rintf(v) && fabsf(v) <= BF16_EXACT_MAX; }
 
-// row norms (fp32 fma chain in index order) + 16-bit image + eligibility.  A workgroup of 64 threads takes 64 rows: the rows
+// Three bf16 pieces of an fp32 value, most significant first, by truncation: v = p0 + p1 + p2 exactly (24 significant bits
+// = 3 x 8; every remainder v - p is exact).  +-inf comes back as (+-inf, 0, 0).
+__device__ __forceinline__ void bf16_split3(float v, uint32_t (&piece)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t b = __float_as_uint(v) & 0xFFFF0000u;
+        piece[i] = b >> 16;
+        v = (b & 0x7FFFFFFFu) == 0x7F800000u ? 0.f : v - __uint_as_float(b);
+    }
+}
+constexpr uint32_t BF16_ONE = 0x3F80u, BF16_SIGN = 0x8000u;
+constexpr uint32_t AUX16 = 8;                   // 16-bit words a base row of the image carries behind its d values (below)
+
+// row norms (fp32 fma chain in index order) + 16-bit image + eligibility.  A workgroup of 64 threads takes ROWS rows: the rows
 // are read coalesced (and converted / checked) by all lanes into LDS, then lane r chains row r's norm out of LDS (row pitch
-// d + 1 floats: conflict-free).  d <= PREP_MAX_D; wider rows take the one-thread-per-row kernel below.
+// d + 1 floats: conflict-free).  d <= PREP_MAX_D; wider rows take the one-thread-per-row kernel below.  ROWS = 64 for the
+// base (millions of rows), 4 for a batch of queries (1024 rows in 64 rows per workgroup were 16 workgroups and 37 us).
+// The image has `pitch16` 16-bit words per row.  With `aux` (the base), words d .. d+7 of a row hold the column's half of the
+// threshold term the bf16 tiles feed to the matrix pipe as a ninth k-step: (-b0, -b1, -b2, 1, 1, 1, 0, 0), b0 + b1 + b2 =
+// |y|^2 / 2 exactly (bf16_split3); the query's half is built by the tile kernel (k_l2_tile16).
 constexpr uint32_t PREP_MAX_D = 128;
+template <uint32_t ROWS>
 __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
-                                                  uint16_t *__restrict__ x16, uint32_t *__restrict__ inexact, uint32_t rows_per_flag) {
-    __shared__ float tile[64 * (PREP_MAX_D + 1)];
-    const size_t r0 = (size_t)blockIdx.x * 64;
-    const uint32_t rows = (uint32_t)(n - r0 < 64 ? n - r0 : 64), total = rows * d, lane = threadIdx.x;
+                                                  uint16_t *__restrict__ x16, uint32_t pitch16, bool aux, uint32_t *__restrict__ inexact,
+                                                  uint32_t rows_per_flag) {
+    __shared__ float tile[ROWS * (PREP_MAX_D + 1)];
+    const size_t r0 = (size_t)blockIdx.x * ROWS;
+    const uint32_t rows = (uint32_t)(n - r0 < ROWS ? n - r0 : ROWS), total = rows * d, lane = threadIdx.x;
     const float *src = x + r0 * d;
     uint32_t bad = 0;                                             // bit (row / rows_per_flag within this block's span) ... kept per lane
     for (uint32_t e = lane; e < total; e += 64) {
         const float v = src[e];
         const uint32_t r = e / d, k = e - r * d;
         tile[r * (d + 1) + k] = v;
-        if (x16) x16[r0 * d + e] = (uint16_t)(__float_as_uint(v) >> 16);      // exact when the value passes; unused otherwise
+        if (x16) x16[(r0 + r) * pitch16 + k] = (uint16_t)(__float_as_uint(v) >> 16);      // exact when the value passes; unused otherwise
         if (inexact && !bf16_exact(v)) bad |= 1u << (rows_per_flag ? ((r0 + r) / rows_per_flag - r0 / rows_per_flag) : 0);
     }
-    if (bad) {                                                    // a block of 64 rows touches at most two flags (rows_per_flag >= 64) or one
+    if (bad) {                                                    // a block of <= 64 rows touches at most two flags (rows_per_flag >= 64) or one
         if (bad & 1u) atomicOr(&inexact[rows_per_flag ? r0 / rows_per_flag : 0], 1u);
         if (bad & 2u) atomicOr(&inexact[r0 / rows_per_flag + 1], 1u);
     }
@@ -102,11 +122,20 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
         float acc = 0.f;
         for (uint32_t k = 0; k < d; ++k) acc = fmaf(row[k], row[k], acc);
         norms[r0 + lane] = acc;
+        if (x16 && aux) {
+            uint32_t b[3];
+            bf16_split3(0.5f * acc, b);
+            u32x4 w;
+            w[0] = (b[0] ^ BF16_SIGN) | ((b[1] ^ BF16_SIGN) << 16);
+            w[1] = (b[2] ^ BF16_SIGN) | (BF16_ONE << 16);
+            w[2] = BF16_ONE | (BF16_ONE << 16);
+            w[3] = 0;
+            *reinterpret_cast<u32x4 *>(x16 + (r0 + lane) * pitch16 + d) = w;        // 16-byte aligned: d and pitch16 are multiples of 8
+        }
     }
 }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;      // 16 bytes in registers (HIP's uint4 struct in an array stays in scratch)
 
 // One 128x128 tile of distances per workgroup (256 threads = 4 waves, each wave a 64x64 quadrant as
 // 2x2 MFMA 32x32 tiles).  Rows of the tile are queries, columns are base rows, so that a stored
@@ -494,43 +523,92 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     l2_tile_f32<FILTER, GEO, FAST, AGG>(p, smem, j % p.n_qtiles, (j / p.n_qtiles) * 8 + xcd);
 }
 
-// Survivors of the bf16 tiles are parked in LDS and written out once per workgroup walk instead of once per tile.  The
-// fp32 epilogue reserves room in the candidate lists with a returning global atomic per wave and tile and sweeps the
-// accumulators twice; at two workgroups per CU nothing covers that round trip (measured by elimination: the tile loop
-// without any epilogue 0.48 ms per search, with the threshold sweep alone 0.59, with reservation and second sweep 0.85).
-// Here a survivor costs one LDS atomic (its slot in the list) in the one sweep that finds it; row-local indices and the
-// global reservation -- one atomic per row with survivors -- are dealt with by flush(), once per walk or when the list
-// runs full.  A survivor that finds the list full (dense early chunks) is appended in global memory on the spot.
+// ---- bf16 tiles (exactly-representable data, d = 64 or 128) ---------------------------------------------------------
+// What the matrix pipe computes here is the FILTER VALUE itself, not the dot product: a ninth k-step adds the threshold,
+//     acc = x.y - |y|^2/2 - R,         R = (|x|^2 - tau)/2 - margin,
+// the column's half coming with the base row (three bf16 pieces behind its d values, k_rows_prep), the row's half built once
+// per walk from the staged thresholds (three pieces of R against three ones).  dist <= tau  <=>  x.y >= (|x|^2 - tau)/2 +
+// |y|^2/2 (all terms half-integers below 2^23 on this path), so a distance can only pass if acc >= 0: the epilogue reads
+// SIGN BITS, one v_alignbit_b32 per accumulator value.  (Before: add, subtract, shift per value on the vector pipe -- with
+// two waves per SIMD the tile walk is bound by the instructions a wave issues, 830 per tile of which 32 were matrix
+// instructions; phase stamps in tools/flat_stamps.py.)
+// Exactness.  While |R| <= 2^22 every partial sum of the nine k-steps is a half-integer of magnitude <= 2^24, the
+// accumulator is exact in any order of addition, the margin is 0 and the filter is the distance test itself.  A larger |R|
+// (tau far above the query norm: data with negative values, or tau = +inf) may round partial sums, by less than
+// 2^-19 |R| in total: margin = max(256, 2^-14 |R|) keeps the filter conservative, and a candidate too many is harmless
+// (k_select orders candidates by their distance).  The DISTANCE of a survivor does not come from the accumulator: a
+// survivor is parked as (row, base id) and flush() recomputes its dot product from the two 16-bit rows, sixteen lanes
+// per survivor (v_dot2c_f32_bf16: integer sums below 2^24, exact in any order) -- the same number, bit for bit, as the
+// fp32 chain.  That costs about 7 instructions per survivor, once per walk, instead of a register-indexed read and ~85
+// instructions inside the tile loop.
+// One workgroup keeps the bf16 image of its 128-query tile in registers (whole k) and walks `group` consecutive 128-row
+// column tiles: a tile of the base image (rows of d values + 8 threshold words = PITCH bytes) is one contiguous block of
+// memory and is copied as such, 16 bytes per lane, into one of two LDS buffers (the odd row pitch in 16-byte units makes
+// ds_read_b128 of 32 consecutive rows conflict-free): while the matrix pipe and the epilogue work on tile t, the loads of
+// tile t+2 are in flight in registers and tile t+1 sits in the other buffer -- one barrier per tile.
+// A query tile with a value that is NOT exactly representable (q_inexact, set on the device) runs the fp32 tile body here.
 struct Pend16 {
-    static constexpr uint32_t CAP = 704;      // 2 x 34 KiB of operands + 1 KiB of rows + this list fit twice into a CU's 160 KiB
-    uint64_t key[CAP];                 // accumulator bits << 32 | base row id; flush() turns it into the (distance, id) key
-    uint32_t loc[CAP];                 // local row; flush() adds the row-local index in the upper half
+    static constexpr uint32_t CAP = 1120;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
+    uint32_t id[CAP];                  // base row
+    uint32_t loc[CAP];                 // local query row; flush() adds the row-local index in the upper half
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
 };
 
-template <class GEO>
+// dot product of two 16-bit rows of D values by ONE lane (the overflow path of the survivor list: rare)
+template <int D>
+__device__ __forceinline__ float dot16_rows(const uint16_t *a, const uint16_t *b) {
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    float s = 0.f;
+    for (int c = 0; c < D / 8; ++c) {
+        const u32x4 va = *reinterpret_cast<const u32x4 *>(a + 8 * c), vb = *reinterpret_cast<const u32x4 *>(b + 8 * c);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t wa = va[w], wb = vb[w];       // through scalars: __builtin_bit_cast applied to va[w] itself reads element 0 four times (hipcc 7.2)
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wa), __builtin_bit_cast(bf16x2, wb), s, false);
+        }
+    }
+    return s;
+}
+
+template <int D>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid) {
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
     __syncthreads();                                              // every append has landed
     const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;   // adds beyond the capacity went to global memory directly
     if (n == 0) return;                                           // workgroup-uniform
-    for (uint32_t e = tid; e < n; e += GEO::THREADS) {
+    for (uint32_t e = tid; e < n; e += 256) {
         const uint32_t row = pd.loc[e];
         pd.loc[e] = row | (atomicAdd(&pd.rcnt[row], 1u) << 16);
     }
     __syncthreads();
-    if (tid < GEO::TM) {
+    if (tid < 128) {
         const uint32_t c = pd.rcnt[tid];
         pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
         pd.rcnt[tid] = 0;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < n; e += GEO::THREADS) {
-        const uint32_t loc = pd.loc[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
-        if (pos < p.cap) {                                       // the distance is formed here, once per survivor, not in the tile sweep
-            const uint64_t raw = pd.key[e];
-            const uint32_t id = (uint32_t)raw;
-            const float dist = fmaf(-2.f, __uint_as_float((uint32_t)(raw >> 32)), sA[2 * row] + p.bn[id]);
+    const uint32_t g = (uint32_t)tid / L, l = (uint32_t)tid % L;
+    for (uint32_t e0 = 0; e0 < n; e0 += G) {
+        const uint32_t e = e0 + g < n ? e0 + g : n - 1;           // the last pass repeats the last survivor in its idle groups
+        const uint32_t loc = pd.loc[e], id = pd.id[e], row = loc & 0xFFFFu;
+        const u32x4 va = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + row) * (size_t)D + 8 * l);
+        const u32x4 vb = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id * (D + AUX16) + 8 * l);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t wa = va[w], wb = vb[w];       // through scalars: __builtin_bit_cast applied to va[w] itself reads element 0 four times (hipcc 7.2)
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wa), __builtin_bit_cast(bf16x2, wb), s, false);
+        }
+        // sum over the L lanes of the group (DPP: quad permutes, then mirrors within 8 and 16 lanes): every lane ends with the total
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
+        if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
+        const uint32_t pos = pd.rbase[row] + (loc >> 16);
+        if (l == 0 && e0 + g < n && pos < p.cap) {
+            const float dist = fmaf(-2.f, s, sA[2 * row] + p.bn[id]);
             p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
         }
     }
@@ -549,98 +627,64 @@ __device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF
 #else
 #define PF_FSTAMP(k) do { } while (0)
 #endif
-// FILTER epilogue of the bf16 tiles (EXACT thresholds, rows prestaged in `sA`: (norm, threshold) pairs and, at 3*TM, the
-// accumulator thresholds).  No barrier inside: the caller's per-tile barrier follows.
-// Two parts.  (1) A branch-free sweep: accumulator >= threshold is the sign of their difference, shifted into one 32-bit
-// word per column block (v_sub_f32 + v_alignbit_b32 per value).  A verdict per row by ballot and scalar branch -- the
-// first version -- made every one of the 32 rows of a lane wait for a vector compare to reach the scalar unit: 3 650
-// cycles per tile in the phase stamps (tools/flat_stamps.py), half of the tile's period, with the vector pipe idle.
-// (2) The rows that hold a survivor anywhere in the wave (OR of the words over the lanes: six DPP steps) are visited by
-// scalar bit tests; a lane reserves room in the list for all its survivors of the tile with ONE returning LDS atomic.
+
+// FILTER epilogue of the bf16 tiles: the accumulators hold the filter value (above), a distance can pass only where the sign
+// bit is clear.  Row s = 16 i + r of a lane ends up in bit 31 - s of the lane's word for its column block; a lane then reserves
+// room in the list for all its survivors of the tile with ONE returning LDS atomic and parks (local row, base id) for each.
+// No barrier inside: the caller's per-tile barrier follows.
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <class GEO, class Stamp = NoStamp>
+template <class GEO, int D, class Stamp = NoStamp>
 __device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&acc)[GEO::MI][GEO::NJ], const float *sA, Pend16 &pd, size_t q0,
                                                    int wm, int tid, const size_t (&col)[GEO::NJ], const bool (&col_ok)[GEO::NJ],
-                                                   const float (&bnv)[GEO::NJ], Stamp stamp = Stamp{}) {
-    constexpr int TM = GEO::TM, MI = GEO::MI, NJ = GEO::NJ;
+                                                   Stamp stamp = Stamp{}) {
+    constexpr int MI = GEO::MI, NJ = GEO::NJ;
     static_assert(MI * 16 == 32, "one verdict word per column block: 32 accumulator rows per lane");
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));       // opaque per call: or hipcc computes the 32 local-row numbers of this lane once, ahead of the
-                                         // caller's tile loop, and keeps them in 32 registers across it (spills)
-    float bnh[NJ];
-    uint32_t fail[NJ];
+    const int lane = tid & 63;
+    uint32_t surv[NJ], cnt = 0;
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) { bnh[jj] = col_ok[jj] ? 0.5f * bnv[jj] : 0.f; fail[jj] = 0; }
+    for (int jj = 0; jj < NJ; ++jj) {
+        uint32_t fail = 0;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r8 = 0; r8 < 16; r8 += 8) {
-            float rqs[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rqs[e] = sA[3 * TM + wm + 32 * i + ((r8 + e) & 3) + 8 * ((r8 + e) >> 2) + 4 * (lane >> 5)];
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    // acc >= t  <=>  the sign of fl(acc - t) is clear (t = +-inf included; t is never NaN: rows past nq carry
-                    // +inf, columns past the end of the chunk 0 and are masked below); row s = 16 i + r ends up in bit 31 - s
-                    const float dlt = acc[i][jj][r8 + e] - (rqs[e] + bnh[jj]);
-                    fail[jj] = __builtin_amdgcn_alignbit(fail[jj], __float_as_uint(dlt), 31);
-                }
-        }
+            for (int r = 0; r < 16; ++r) fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(acc[i][jj][r]), 31);
+        surv[jj] = col_ok[jj] ? ~fail : 0u;                              // columns past the end of the chunk re-read the last valid row
+        cnt += __popc(surv[jj]);
     }
-    uint32_t surv[NJ], mine = 0, cnt = 0;
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) { surv[jj] = col_ok[jj] ? ~fail[jj] : 0u; mine |= surv[jj]; cnt += __popc(surv[jj]); }
     stamp(4);
-    const uint32_t rows_hit = __reduce_or_sync(~0ull, mine);           // wave-uniform: bit 31 - s set = row s holds a survivor
-    if (rows_hit == 0) { stamp(5); return; }
+    if (__ballot(cnt != 0) == 0) { stamp(5); return; }
     uint32_t slot = cnt ? atomicAdd(&pd.n, cnt) : 0u;                   // this lane's survivors take slot, slot + 1, ...
     stamp(5);
-    // one copy of the parking code: the accumulator row is picked by a wave-uniform register index (s_set_gpr_idx_on), not by
-    // 32 unrolled blocks -- rows with a survivor are few in the long late chunks, and a block per row was 30 KiB of code
-    // (the accumulators pass through an empty asm first: indexed straight out of the array `acc`, hipcc turns the read into a load
-    // from a computed address before it has unrolled the loops around the array, and the whole array then lives in scratch)
-    f32x16 av[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) { av[i][jj] = acc[i][jj]; asm volatile("" : "+v"(av[i][jj])); }
-    for (uint32_t h = rows_hit; h;) {
-        const int b = 31 - __builtin_clz(h);                            // scalar: row s = 31 - b
-        h &= ~(1u << b);
-        const int s = 31 - b, i = s >> 4, r = s & 15;
-        const int lrow = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            float a_lo = av[0][jj][r], a_hi = av[MI - 1][jj][r];       // two indexed moves; the empty asm keeps hipcc from selecting between
-            asm volatile("" : "+v"(a_lo), "+v"(a_hi));                  // the two 16-register rows first (16 v_cndmask)
-            const float a = i ? a_hi : a_lo;
-            if (!((surv[jj] >> b) & 1u)) continue;
-            const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
+    for (int jj = 0; jj < NJ; ++jj) {
+        const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
+        for (uint32_t m = surv[jj]; m;) {                               // per lane: mostly zero or one bit in the long late chunks
+            const int b = 31 - __builtin_clz(m);
+            m &= ~(1u << b);
+            const int s = 31 - b, r = s & 15;
+            const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
             const uint32_t e2 = slot++;
-            if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.key[e2] = ((uint64_t)__float_as_uint(a) << 32) | id; pd.loc[e2] = (uint32_t)lrow; }
-            else {                                               // list full: straight to the candidate list
-                const float dist = fmaf(-2.f, a, sA[2 * lrow] + bnv[jj]);
+            if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.id[e2] = id; pd.loc[e2] = lrow; }
+            else {                                                       // list full: straight to the candidate list
                 const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
-                if (pos < p.cap) p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+                if (pos < p.cap) {
+                    const float xy = dot16_rows<D>(p.xq16 + (q0 + lrow) * (size_t)D, p.xb16 + (size_t)id * (D + AUX16));
+                    const float dist = fmaf(-2.f, xy, sA[2 * lrow] + p.bn[id]);
+                    p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+                }
             }
         }
     }
 }
 
-// ---- bf16 tiles (exactly-representable data, d = 64 or 128) ---------------------------------------------------------
-// One workgroup keeps the bf16 image of its 128-query tile in LDS (whole k) and walks `group` consecutive 128-row column
-// tiles: while the matrix pipe and the epilogue work on tile t, the global loads of tile t+1 are in flight in registers.
-// Per tile that leaves an LDS write, two barriers, 32 matrix instructions per wave and the filtering epilogue; the query
-// tile is fetched once per `group` tiles.  LDS rows carry 16 bytes of padding: conflict-free ds_write_b128 / ds_read_b128.
-// A query tile with a value that is NOT exactly representable (q_inexact, set on the device) runs the fp32 tile body here.
 template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
 __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = GeoBatch;
-    constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = 128 * 2 + 16;
-    static_assert(F32_TILE_LDS<GEO> <= (size_t)(TM + TN) * PITCH, "the fp32 fallback borrows the bf16 tiles' LDS");
-    __shared__ __align__(16) char smem[(TM + TN) * PITCH];
+    constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
+    constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
+    constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
+    static_assert(PITCH % 32 == 16 && TN == 128 && TM == 128, "odd row pitch in 16-byte units; 128 x 128 tiles");
+    __shared__ __align__(16) char smem[SMEM];
     __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
     __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -655,9 +699,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     const uint32_t ct0 = grp * group, ct1 = ct0 + group < n_ct ? ct0 + group : n_ct;
     if (p.q_inexact[qt]) {                                          // workgroup-uniform: fp32 operands for this query tile
         for (uint32_t ct = ct0; ct < ct1; ++ct) {
-#ifndef PF_DBG_NO_FALLBACK
             l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
-#endif
             __syncthreads();
         }
         return;
@@ -686,23 +728,23 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         // the rows of the query tile are the same for every column tile: staged once
         l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
     }
-    // staging of a column tile: 16 bytes per lane, a row of D*2 bytes covered by D/8 consecutive lanes
-    constexpr uint32_t segs = D / 8, rows_per_sweep = 256 / segs, sweeps = TN / rows_per_sweep;     // D = 128: 16, 16, 8
-    const uint32_t srow = tid / segs, sseg = tid % segs;
-    u32x4 vb[sweeps];
+    // a column tile is PIECES consecutive 16-byte pieces of the image (the allocation is padded by one tile of zero rows, so
+    // the last tile of the base reads in bounds): lane t copies pieces t, t + 256, ...
+    u32x4 vb[SWEEPS + (REM ? 1 : 0)];
     float bn_next[NJ];
-    // operands AND column norms of a tile are requested one tile ahead of their LDS write, two tiles ahead of their use
     auto fetch_b = [&](uint32_t ct) {
-        const size_t c0 = (size_t)ct * TN;
-        const uint32_t c_valid = (uint32_t)(p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN);
-        const uint16_t *bbase = p.xb16 + (p.nb_first + c0) * (size_t)D;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.xb16 + (p.nb_first + (size_t)ct * TN) * (size_t)(D + AUX16)) + tid;
 #pragma unroll
-        for (uint32_t it = 0; it < sweeps; ++it) {
-            const uint32_t r = srow + rows_per_sweep * it;
-            vb[it] = *reinterpret_cast<const u32x4 *>(bbase + (r < c_valid ? r : c_valid - 1) * D + sseg * 8);
-        }
+        for (uint32_t it = 0; it < SWEEPS; ++it) vb[it] = src[256 * it];
+        if (REM && (uint32_t)tid < REM) vb[SWEEPS] = src[256 * SWEEPS];
     };
-    auto fetch_bn = [&](uint32_t ct) {
+    auto commit_b = [&](char *buf) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(buf) + tid;
+#pragma unroll
+        for (uint32_t it = 0; it < SWEEPS; ++it) dst[256 * it] = vb[it];
+        if (REM && (uint32_t)tid < REM) dst[256 * SWEEPS] = vb[SWEEPS];
+    };
+    auto fetch_bn = [&](uint32_t ct) {                               // column norms: the unfiltered (bootstrap) epilogue forms distances
         const size_t c0 = (size_t)ct * TN;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
@@ -710,15 +752,30 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
-    auto commit_b = [&](char *buf) {
-#pragma unroll
-        for (uint32_t it = 0; it < sweeps; ++it) *reinterpret_cast<u32x4 *>(buf + (srow + rows_per_sweep * it) * PITCH + sseg * 16) = vb[it];
-    };
     fetch_b(ct0);
-    fetch_bn(ct0);
+    if constexpr (!FILTER) fetch_bn(ct0);
     commit_b(sB16_0);
     if (ct0 + 1 < ct1) fetch_b(ct0 + 1);
     __syncthreads();
+    // the row half of the threshold k-step: lanes 0..31 carry (1, 1, 1, -r0, -r1, -r2, 0, 0) of their row for k = 0..7, lanes
+    // 32..63 (k = 8..15) zeros; r0 + r1 + r2 = R (header comment)
+    bf16x8 a_aux[MI];
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float rq = stage[3 * TM + wm + 32 * i + (lane & 31)];           // (|x|^2 - tau) / 2; +inf for rows past nq
+            const float big = fabsf(rq) * 0x1p-14f, margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
+            uint32_t r[3];
+            bf16_split3(fabsf(rq) == INFINITY ? rq : rq - margin, r);
+            u32x4 w;
+            w[0] = BF16_ONE | (BF16_ONE << 16);
+            w[1] = BF16_ONE | ((r[0] ^ BF16_SIGN) << 16);
+            w[2] = (r[1] ^ BF16_SIGN) | ((r[2] ^ BF16_SIGN) << 16);
+            w[3] = 0;
+            if (lane >= 32) w = u32x4{0, 0, 0, 0};
+            a_aux[i] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
 #ifdef PF_FLAT_STAMPS
     const bool fs_on = FILTER && p.nb_count == 524288 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
 #endif
@@ -734,10 +791,10 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         for (int jj = 0; jj < NJ; ++jj) {
             col[jj] = c0 + wn + 32 * jj + (lane & 31);
             col_ok[jj] = col[jj] < p.nb_count;
-            bnv[jj] = bn_next[jj];
+            bnv[jj] = FILTER ? 0.f : bn_next[jj];
         }
         if (ct + 2 < ct1) fetch_b(ct + 2);                          // in flight under this tile's matrix work and epilogue
-        if (ct + 1 < ct1) fetch_bn(ct + 1);
+        if constexpr (!FILTER) { if (ct + 1 < ct1) fetch_bn(ct + 1); }
         f32x16 acc[MI][NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -747,7 +804,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
         // column fragments of k-step s+1 are read from LDS while the matrix instructions of step s run (fenced: left to
         // itself hipcc hoists every fragment read of the tile to the top)
-        const char *fb = (cur ? sB16_1 : sB16_0) + (wn + (lane & 31)) * PITCH + (lane >> 5) * 16;
+        const char *fbx = (cur ? sB16_1 : sB16_0) + (wn + (lane & 31)) * PITCH, *fb = fbx + (lane >> 5) * 16;
         bf16x8 b[2][NJ];
         PF_FSTAMP(2);
 #pragma unroll
@@ -758,6 +815,9 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             if (ks + 1 < D / 16) {
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH + (ks + 1) * 32);
+            } else if constexpr (FILTER) {                           // the threshold words behind the row: same 16 bytes for both lane halves
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fbx + 32 * jj * PITCH + D * 2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -766,6 +826,13 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (FILTER) {
+            constexpr int c = (D / 16) & 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux[i], b[c][jj], acc[i][jj], 0, 0, 0);
+        }
         // q0 made opaque per tile: otherwise hipcc hoists the row addresses (q0 + row) * cap of the (rare) key stores out of
         // the tile loop and keeps them alive across it
         size_t q0t = q0;
@@ -773,20 +840,20 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         PF_FSTAMP(3);
         if constexpr (FILTER) {
 #ifdef PF_FLAT_STAMPS
-            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, bnv, [&](int k) { PF_FSTAMP(k); });
+            l2_tile_epilogue16<GEO, D>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, [&](int k) { PF_FSTAMP(k); });
 #else
-            l2_tile_epilogue16<GEO>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, bnv);
+            l2_tile_epilogue16<GEO, D>(p, acc, stage, pend, q0t, wm, tid, col, col_ok);
 #endif
             PF_FSTAMP(6);
             __syncthreads();                                        // the tile's one barrier: the other buffer is complete, the list settled
             PF_FSTAMP(7);
-            if (pend.n > Pend16::CAP / 2) pend16_flush<GEO>(p, pend, stage, q0, tid);   // workgroup-uniform
+            if (pend.n > Pend16::CAP / 3) pend16_flush<D>(p, pend, stage, q0, tid);   // workgroup-uniform
         } else {
             l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
             __syncthreads();
         }
     }
-    if constexpr (FILTER) pend16_flush<GEO>(p, pend, stage, q0, tid);
+    if constexpr (FILTER) pend16_flush<D>(p, pend, stage, q0, tid);
 }
 
 // ---- selection -----------------------------------------------------------------------------------
@@ -1223,13 +1290,15 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
         // row norms; and, where the shape allows the bf16 loop, the 16-bit image with its value-by-value exactness check
         uint32_t *flag = nullptr;
         const bool try16 = (d == 64 || d == 128) && getenv("PF_FLAT_NO_BF16") == nullptr;
-        if (try16 && (hipMalloc((void **)&f->xb16, nb * (size_t)d * 2) != hipSuccess || hipMalloc((void **)&flag, 4) != hipSuccess ||
-                      hipMemset(flag, 0, 4) != hipSuccess)) {
+        // image rows carry AUX16 threshold words behind their d values; one tile of zero rows pads the end (k_l2_tile16 copies whole tiles)
+        const size_t bytes16 = (nb + 128) * (size_t)(d + AUX16) * 2;
+        if (try16 && (hipMalloc((void **)&f->xb16, bytes16) != hipSuccess || hipMemset(f->xb16, 0, bytes16) != hipSuccess ||
+                      hipMalloc((void **)&flag, 4) != hipSuccess || hipMemset(flag, 0, 4) != hipSuccess)) {
             (void)hipGetLastError();                                  // no room for the image: the fp32 path needs none
             if (f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }
             if (flag) { (void)hipFree(flag); flag = nullptr; }
         }
-        if (d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, flag, 0u);
+        if (d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep<64>, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
         else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1302,8 +1371,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
     if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
-    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr,
-                                               b16 ? qbad : nullptr, 128u);
+    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep<4>, dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, f->d,
+                                               false, b16 ? qbad : nullptr, 128u);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
     t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad;

@@ -30,7 +30,7 @@ ok = s[..., 0] > 0
 nt = int(ok[0, 0].sum())
 print("tiles stamped per workgroup:", nt)
 s = s[:, :, :nt]
-names = ["commit_b (waits for tile t+1 loads)", "addresses, fetch t+2, zero acc", "fragment reads + 32 MFMA", "epilogue: sweep", "epilogue: reduce + reserve", "epilogue: rows with survivors", "barrier"]
+names = ["commit_b (waits for tile t+1 loads)", "addresses, fetch t+2, zero acc", "fragment reads + 36 MFMA", "epilogue: sign sweep", "epilogue: reserve", "epilogue: park survivors", "barrier"]
 for k in range(K - 1):
     d = s[..., k + 1] - s[..., k]
     print("%-40s mean %8.0f  p50 %8.0f  max %8.0f" % (names[k], d.mean(), np.median(d), d.max()))
