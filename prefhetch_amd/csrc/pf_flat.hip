@@ -548,79 +548,107 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 // tile t+2 are in flight in registers and tile t+1 sits in the other buffer -- one barrier per tile.
 // A query tile with a value that is NOT exactly representable (q_inexact, set on the device) runs the fp32 tile body here.
 struct Pend16 {
-    static constexpr uint32_t CAP = 1120;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
+    static constexpr uint32_t CAP = 1112;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
     uint32_t id[CAP];                  // base row
     uint32_t loc[CAP];                 // local query row; flush() adds the row-local index in the upper half
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
 };
 
-// dot product of two 16-bit rows of D values by ONE lane (the overflow path of the survivor list: rare)
-template <int D>
-__device__ __forceinline__ float dot16_rows(const uint16_t *a, const uint16_t *b) {
-    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-    float s = 0.f;
-    for (int c = 0; c < D / 8; ++c) {
-        const u32x4 va = *reinterpret_cast<const u32x4 *>(a + 8 * c), vb = *reinterpret_cast<const u32x4 *>(b + 8 * c);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t wa = va[w], wb = vb[w];       // through scalars: __builtin_bit_cast applied to va[w] itself reads element 0 four times (hipcc 7.2)
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wa), __builtin_bit_cast(bf16x2, wb), s, false);
-        }
-    }
-    return s;
-}
-
-template <int D>
-__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid) {
+// The verdict words of MT tiles (surv[u][jj]: tile ct_base + u, column block jj; bit 31 - s = accumulator row s of this lane)
+// are decoded here, once per MT tiles, by the lane that owns them: each survivor takes a slot of the list and its index
+// within its query row (LDS atomics), a row with survivors reserves its range of the candidate list with ONE global atomic,
+// then sixteen lanes per survivor recompute the dot product from the two 16-bit rows and the group's first lane writes the
+// key.  A list too small for everything (dense early chunks) is worked off in rounds: the words not yet decoded stay in
+// the registers.  Barriers inside: call from all threads.
+template <int D, int MT, int NJ>
+__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
+                                             uint32_t ct_base, int wm, int wn) {
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
-    __syncthreads();                                              // every append has landed
-    const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;   // adds beyond the capacity went to global memory directly
-    if (n == 0) return;                                           // workgroup-uniform
-    for (uint32_t e = tid; e < n; e += 256) {
-        const uint32_t row = pd.loc[e];
-        pd.loc[e] = row | (atomicAdd(&pd.rcnt[row], 1u) << 16);
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const uint32_t c = pd.rcnt[tid];
-        pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
-        pd.rcnt[tid] = 0;
-    }
-    __syncthreads();
-    const uint32_t g = (uint32_t)tid / L, l = (uint32_t)tid % L;
-    for (uint32_t e0 = 0; e0 < n; e0 += G) {
-        const uint32_t e = e0 + g < n ? e0 + g : n - 1;           // the last pass repeats the last survivor in its idle groups
-        const uint32_t loc = pd.loc[e], id = pd.id[e], row = loc & 0xFFFFu;
-        const u32x4 va = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + row) * (size_t)D + 8 * l);
-        const u32x4 vb = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id * (D + AUX16) + 8 * l);
-        float s = 0.f;
+    const int lane = tid & 63;
+    uint32_t left = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t wa = va[w], wb = vb[w];       // through scalars: __builtin_bit_cast applied to va[w] itself reads element 0 four times (hipcc 7.2)
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wa), __builtin_bit_cast(bf16x2, wb), s, false);
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
+    while (__syncthreads_or(left != 0)) {                         // (the barrier: the list is empty, every row count zero)
+        uint32_t slot = left ? atomicAdd(&pd.n, left) : 0u;
+        uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
+        take = left < take ? left : take;
+        left -= take;
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                uint32_t m = surv[u][jj];
+                const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * 128 + wn + 32 * jj + (lane & 31));
+                while (m && take) {
+                    const int b = 31 - __builtin_clz(m);
+                    m &= ~(1u << b);
+                    const int s = 31 - b, r = s & 15;
+                    const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                    pd.id[slot] = id;
+                    pd.loc[slot] = lrow | (atomicAdd(&pd.rcnt[lrow], 1u) << 16);
+                    ++slot; --take;
+                }
+                surv[u][jj] = m;
+            }
+        __syncthreads();
+        const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
+        // U survivors per group and pass: their rows are requested first, and in the first pass the per-row reservations (a
+        // returning global atomic per row with survivors) travel at the same time -- one round trip to memory, not two
+        constexpr int U = 4;
+        const uint32_t g = (uint32_t)tid / L, l = (uint32_t)tid % L;
+        for (uint32_t e0 = 0; e0 < n; e0 += G * U) {
+            u32x4 va[U], vb[U];
+            uint32_t loc[U], id[U];
+            float bnv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e = e0 + u * G + g < n ? e0 + u * G + g : n - 1;     // idle groups of the last pass repeat the last survivor
+                loc[u] = pd.loc[e]; id[u] = pd.id[e];
+                va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + (loc[u] & 0xFFFFu)) * (size_t)D + 8 * l);
+                vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
+                bnv[u] = p.bn[id[u]];
+            }
+            if (e0 == 0) {                                            // workgroup-uniform
+                if (tid < 128) {
+                    const uint32_t c = pd.rcnt[tid];
+                    pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
+                    pd.rcnt[tid] = 0;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t wa = va[u][w], wb = vb[u][w];     // through scalars: __builtin_bit_cast applied to va[u][w] itself reads element 0 four times (hipcc 7.2)
+                    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wa), __builtin_bit_cast(bf16x2, wb), s, false);
+                }
+                // sum over the L lanes of the group (DPP: quad permutes, then mirrors within 8 and 16 lanes): every lane ends with the total
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
+                if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
+                const uint32_t row = loc[u] & 0xFFFFu, pos = pd.rbase[row] + (loc[u] >> 16);
+                if (l == 0 && e0 + u * G + g < n && pos < p.cap) {
+                    const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
+                    p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id[u]);
+                }
+            }
         }
-        // sum over the L lanes of the group (DPP: quad permutes, then mirrors within 8 and 16 lanes): every lane ends with the total
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
-        if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
-        const uint32_t pos = pd.rbase[row] + (loc >> 16);
-        if (l == 0 && e0 + g < n && pos < p.cap) {
-            const float dist = fmaf(-2.f, s, sA[2 * row] + p.bn[id]);
-            p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
-        }
+        __syncthreads();
+        if (tid == 0) pd.n = 0;
     }
-    __syncthreads();
-    if (tid == 0) pd.n = 0;
-    __syncthreads();
 }
 
 #ifdef PF_FLAT_STAMPS        // experiments (tools/flat_stamps.py): s_memtime at the phase boundaries of the tile walk
 #define PF_FS_WGS 32
 #define PF_FS_TILES 16
-#define PF_FS_K 8
+#define PF_FS_K 6
 __device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF_FS_K];
 #define PF_FSTAMP(k) do { if (fs_on && (tid & 63) == 0 && ct - ct0 < PF_FS_TILES) \
     pf_flat_stamp_buf[(((blockIdx.x - 2048) * 4 + (tid >> 6)) * PF_FS_TILES + (ct - ct0)) * PF_FS_K + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -629,18 +657,12 @@ __device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF
 #endif
 
 // FILTER epilogue of the bf16 tiles: the accumulators hold the filter value (above), a distance can pass only where the sign
-// bit is clear.  Row s = 16 i + r of a lane ends up in bit 31 - s of the lane's word for its column block; a lane then reserves
-// room in the list for all its survivors of the tile with ONE returning LDS atomic and parks (local row, base id) for each.
-// No barrier inside: the caller's per-tile barrier follows.
-struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <class GEO, int D, class Stamp = NoStamp>
-__device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&acc)[GEO::MI][GEO::NJ], const float *sA, Pend16 &pd, size_t q0,
-                                                   int wm, int tid, const size_t (&col)[GEO::NJ], const bool (&col_ok)[GEO::NJ],
-                                                   Stamp stamp = Stamp{}) {
+// bit is clear.  Row s = 16 i + r of a lane ends up in bit 31 - s of the lane's word for its column block.  That is all a tile
+// does about its survivors: the words stay in registers until flush() decodes them.
+template <class GEO>
+__device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::NJ], const bool (&col_ok)[GEO::NJ], uint32_t (&surv)[GEO::NJ]) {
     constexpr int MI = GEO::MI, NJ = GEO::NJ;
     static_assert(MI * 16 == 32, "one verdict word per column block: 32 accumulator rows per lane");
-    const int lane = tid & 63;
-    uint32_t surv[NJ], cnt = 0;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         uint32_t fail = 0;
@@ -648,35 +670,13 @@ __device__ __forceinline__ void l2_tile_epilogue16(const TileArgs &p, f32x16 (&a
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(acc[i][jj][r]), 31);
-        surv[jj] = col_ok[jj] ? ~fail : 0u;                              // columns past the end of the chunk re-read the last valid row
-        cnt += __popc(surv[jj]);
-    }
-    stamp(4);
-    if (__ballot(cnt != 0) == 0) { stamp(5); return; }
-    uint32_t slot = cnt ? atomicAdd(&pd.n, cnt) : 0u;                   // this lane's survivors take slot, slot + 1, ...
-    stamp(5);
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const uint32_t id = (uint32_t)(p.nb_first + col[jj]);
-        for (uint32_t m = surv[jj]; m;) {                               // per lane: mostly zero or one bit in the long late chunks
-            const int b = 31 - __builtin_clz(m);
-            m &= ~(1u << b);
-            const int s = 31 - b, r = s & 15;
-            const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-            const uint32_t e2 = slot++;
-            if (__builtin_expect(e2 < Pend16::CAP, 1)) { pd.id[e2] = id; pd.loc[e2] = lrow; }
-            else {                                                       // list full: straight to the candidate list
-                const uint32_t pos = atomicAdd(&p.cand_cnt[q0 + lrow], 1u);
-                if (pos < p.cap) {
-                    const float xy = dot16_rows<D>(p.xq16 + (q0 + lrow) * (size_t)D, p.xb16 + (size_t)id * (D + AUX16));
-                    const float dist = fmaf(-2.f, xy, sA[2 * lrow] + p.bn[id]);
-                    p.cand[(q0 + lrow) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
-                }
-            }
-        }
+        surv[jj] = col_ok[jj] ? ~fail : 0u;                              // columns past the end of the chunk re-read rows of the next one
     }
 }
 
+#ifndef PF_FLAT_MT
+#define PF_FLAT_MT 8
+#endif
 template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
 __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = GeoBatch;
@@ -729,20 +729,21 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
     }
     // a column tile is PIECES consecutive 16-byte pieces of the image (the allocation is padded by one tile of zero rows, so
-    // the last tile of the base reads in bounds): lane t copies pieces t, t + 256, ...
-    u32x4 vb[SWEEPS + (REM ? 1 : 0)];
+    // the last tile of the base reads in bounds) and is copied as such by LDS-DMA (global_load_lds_dwordx4: no registers, no
+    // ds_write): lane t moves pieces t, t + 256, ...; one wave-instruction fills 1 KiB of LDS from its wave-uniform base.
+    // Tile t+1 is requested at the top of tile t, into the buffer whose readers passed the barrier that ended tile t-1, and
+    // waited for (vmcnt(0)) before the barrier that ends tile t.
     float bn_next[NJ];
-    auto fetch_b = [&](uint32_t ct) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.xb16 + (p.nb_first + (size_t)ct * TN) * (size_t)(D + AUX16)) + tid;
+    auto stage_b = [&](uint32_t ct, char *buf) {
+        const char *src = reinterpret_cast<const char *>(p.xb16 + (p.nb_first + (size_t)ct * TN) * (size_t)(D + AUX16)) + tid * 16;
+        char *dst = buf + wave * 1024;
 #pragma unroll
-        for (uint32_t it = 0; it < SWEEPS; ++it) vb[it] = src[256 * it];
-        if (REM && (uint32_t)tid < REM) vb[SWEEPS] = src[256 * SWEEPS];
-    };
-    auto commit_b = [&](char *buf) {
-        u32x4 *dst = reinterpret_cast<u32x4 *>(buf) + tid;
-#pragma unroll
-        for (uint32_t it = 0; it < SWEEPS; ++it) dst[256 * it] = vb[it];
-        if (REM && (uint32_t)tid < REM) dst[256 * SWEEPS] = vb[SWEEPS];
+        for (uint32_t it = 0; it < SWEEPS; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4096 * it),
+                                             (__attribute__((address_space(3))) void *)(dst + 4096 * it), 16, 0, 0);
+        if (REM && (uint32_t)tid < REM)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4096 * SWEEPS),
+                                             (__attribute__((address_space(3))) void *)(dst + 4096 * SWEEPS), 16, 0, 0);
     };
     auto fetch_bn = [&](uint32_t ct) {                               // column norms: the unfiltered (bootstrap) epilogue forms distances
         const size_t c0 = (size_t)ct * TN;
@@ -752,10 +753,9 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
-    fetch_b(ct0);
+    stage_b(ct0, sB16_0);
     if constexpr (!FILTER) fetch_bn(ct0);
-    commit_b(sB16_0);
-    if (ct0 + 1 < ct1) fetch_b(ct0 + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the row half of the threshold k-step: lanes 0..31 carry (1, 1, 1, -r0, -r1, -r2, 0, 0) of their row for k = 0..7, lanes
     // 32..63 (k = 8..15) zeros; r0 + r1 + r2 = R (header comment)
@@ -779,11 +779,19 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #ifdef PF_FLAT_STAMPS
     const bool fs_on = FILTER && p.nb_count == 524288 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
 #endif
+    // MT tiles between two flushes: their verdict words stay in registers (a 16-register vector written through a wave-uniform
+    // index: the tile loop stays rolled -- unrolled MT times it ran out of registers, and a single scratch reload inside the
+    // loop makes hipcc wait for vmcnt(0), i.e. for the LDS-DMA of the next tile, before the matrix work)
+    constexpr int MT = PF_FLAT_MT;
+    using survx = __attribute__((ext_vector_type(MT * NJ))) uint32_t;
+    survx sv;
+#pragma unroll
+    for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
     for (uint32_t ct = ct0; ct < ct1; ++ct) {
-        const uint32_t cur = (ct - ct0) & 1u;
+        const uint32_t u = (ct - ct0) % MT, cur = (ct - ct0) & 1u;
+        char *const buf_cur = cur ? sB16_1 : sB16_0, *const buf_nxt = cur ? sB16_0 : sB16_1;
         PF_FSTAMP(0);
-        // tile ct+1 goes into the other buffer: its last readers (tile ct-1) passed the barrier that ended that tile
-        if (ct + 1 < ct1) commit_b(cur ? sB16_0 : sB16_1);
+        if (ct + 1 < ct1) stage_b(ct + 1, buf_nxt);                   // in flight under this tile's matrix work and epilogue
         PF_FSTAMP(1);
         const size_t c0 = (size_t)ct * TN;
         size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
@@ -793,7 +801,6 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             col_ok[jj] = col[jj] < p.nb_count;
             bnv[jj] = FILTER ? 0.f : bn_next[jj];
         }
-        if (ct + 2 < ct1) fetch_b(ct + 2);                          // in flight under this tile's matrix work and epilogue
         if constexpr (!FILTER) { if (ct + 1 < ct1) fetch_bn(ct + 1); }
         f32x16 acc[MI][NJ];
 #pragma unroll
@@ -804,7 +811,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
         // column fragments of k-step s+1 are read from LDS while the matrix instructions of step s run (fenced: left to
         // itself hipcc hoists every fragment read of the tile to the top)
-        const char *fbx = (cur ? sB16_1 : sB16_0) + (wn + (lane & 31)) * PITCH, *fb = fbx + (lane >> 5) * 16;
+        const char *fbx = buf_cur + (wn + (lane & 31)) * PITCH, *fb = fbx + (lane >> 5) * 16;
         bf16x8 b[2][NJ];
         PF_FSTAMP(2);
 #pragma unroll
@@ -833,27 +840,33 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux[i], b[c][jj], acc[i][jj], 0, 0, 0);
         }
-        // q0 made opaque per tile: otherwise hipcc hoists the row addresses (q0 + row) * cap of the (rare) key stores out of
-        // the tile loop and keeps them alive across it
-        size_t q0t = q0;
-        asm volatile("" : "+s"(q0t));
         PF_FSTAMP(3);
         if constexpr (FILTER) {
-#ifdef PF_FLAT_STAMPS
-            l2_tile_epilogue16<GEO, D>(p, acc, stage, pend, q0t, wm, tid, col, col_ok, [&](int k) { PF_FSTAMP(k); });
-#else
-            l2_tile_epilogue16<GEO, D>(p, acc, stage, pend, q0t, wm, tid, col, col_ok);
-#endif
-            PF_FSTAMP(6);
-            __syncthreads();                                        // the tile's one barrier: the other buffer is complete, the list settled
-            PF_FSTAMP(7);
-            if (pend.n > Pend16::CAP / 3) pend16_flush<D>(p, pend, stage, q0, tid);   // workgroup-uniform
+            uint32_t s1[NJ];
+            l2_tile_verdicts16<GEO>(acc, col_ok, s1);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj];   // wave-uniform index: v_movreld
+            PF_FSTAMP(4);
         } else {
+            // q0 made opaque per tile: otherwise hipcc hoists the row addresses of the slab stores out of the tile loop
+            size_t q0t = q0;
+            asm volatile("" : "+s"(q0t));
             l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
-            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of tile ct+1 have landed
+        __syncthreads();                                                // the tile's one barrier: the other buffer is complete
+        PF_FSTAMP(5);
+        if constexpr (FILTER) {
+            if (u == MT - 1 || ct + 1 == ct1) {                         // workgroup-uniform
+                uint32_t surv[MT][NJ];
+#pragma unroll
+                for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn);
+#pragma unroll
+                for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
+            }
         }
     }
-    if constexpr (FILTER) pend16_flush<D>(p, pend, stage, q0, tid);
 }
 
 // ---- selection -----------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ for _ in range(3):
     idx.search(xq, 200)
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
-WGS, TILES, K = 32, 16, 8
+WGS, TILES, K = 32, 16, 6
 buf = np.zeros(WGS * 4 * TILES * K, dtype=np.uint64)
 rc = lib.pf_flat_debug_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 assert rc == 0, rc
@@ -30,7 +30,7 @@ ok = s[..., 0] > 0
 nt = int(ok[0, 0].sum())
 print("tiles stamped per workgroup:", nt)
 s = s[:, :, :nt]
-names = ["commit_b (waits for tile t+1 loads)", "addresses, fetch t+2, zero acc", "fragment reads + 36 MFMA", "epilogue: sign sweep", "epilogue: reserve", "epilogue: park survivors", "barrier"]
+names = ["LDS-DMA requests for tile t+1", "addresses, zero acc", "fragment reads + 36 MFMA", "sign sweep", "vmcnt(0) + barrier"]
 for k in range(K - 1):
     d = s[..., k + 1] - s[..., k]
     print("%-40s mean %8.0f  p50 %8.0f  max %8.0f" % (names[k], d.mean(), np.median(d), d.max()))
