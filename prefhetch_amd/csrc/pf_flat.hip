@@ -991,16 +991,10 @@ __device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, ui
 // histogram, most significant byte first), then everything below it and everything equal to it is collected -- the
 // caller's final sort of those few keys settles the order and, among equal distances, the smaller ids.  Returns false
 // (nothing touched) when the ties at the k-th distance would not fit the reservoir; the reservoir scan handles that.
-template <uint32_t THREADS>
-__device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, uint32_t *hist, uint32_t *ctl, uint32_t k, const float *row,
-                                                size_t nb_first, uint32_t n, int tid) {
-    constexpr int VPT = 8192 / THREADS;                              // the chunk (at most 8192 rows) lives in registers: one trip to memory
-    uint32_t u[VPT];
-#pragma unroll
-    for (int e = 0; e < VPT; ++e) {
-        const uint32_t col = tid + e * THREADS;
-        u[e] = col < n ? __float_as_uint(row[col]) : 0xFFFFFFFFu;    // the filler is above every distance (and above NaN patterns in use)
-    }
+// Bit pattern of the k-th smallest of n non-negative fp32 values held in registers (value e of thread t is element
+// t + e * THREADS; elements >= n are ignored): four passes of a 256-bin LDS histogram, most significant byte first.
+template <uint32_t THREADS, int VPT>
+__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&u)[VPT], uint32_t n, uint32_t k, uint32_t *hist, uint32_t *ctl, int tid) {
     uint32_t prefix = 0, mask = 0, need = k;
     for (int pass = 3; pass >= 0; --pass) {
         for (uint32_t b = tid; b < 256; b += THREADS) hist[b] = 0;
@@ -1036,6 +1030,25 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
         prefix = ctl[0]; need = ctl[1]; mask |= 0xFFu << (8 * pass);
         __syncthreads();
     }
+    return prefix;
+}
+
+// Bootstrap without sorting the whole chunk: the k-th smallest distance of the slab row is found by radix selection on
+// the fp32 bit pattern (distances are >= 0, so the bit patterns order like the values), then everything below it and
+// everything equal to it is collected -- the caller's final sort of those few keys settles the order and, among equal
+// distances, the smaller ids.  Returns false (nothing touched) when the ties at the k-th distance would not fit the
+// reservoir; the reservoir scan handles that.
+template <uint32_t THREADS>
+__device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, uint32_t *hist, uint32_t *ctl, uint32_t k, const float *row,
+                                                size_t nb_first, uint32_t n, int tid) {
+    constexpr int VPT = 8192 / THREADS;                              // the chunk (at most 8192 rows) lives in registers: one trip to memory
+    uint32_t u[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t col = tid + e * THREADS;
+        u[e] = col < n ? __float_as_uint(row[col]) : 0xFFFFFFFFu;    // the filler is above every distance (and above NaN patterns in use)
+    }
+    const uint32_t prefix = radix_kth<THREADS, VPT>(u, n, k, hist, ctl, tid);
     // prefix = bit pattern of the k-th smallest distance; count what is below / equal
     if (tid == 0) { ctl[2] = 0; }
     __syncthreads();
@@ -1052,6 +1065,35 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
     }
     __syncthreads();
     return true;
+}
+
+// Before a merge is sorted: the k-th smallest distance among the n keys in LDS by radix selection, then only the keys at
+// or below it (k of them plus ties) move to the front -- the sort that orders them (and settles ties by id) runs on the next
+// power of two above k instead of above k + candidates (256 keys instead of 1024 at k = 200: a fifth of the work).
+template <uint32_t THREADS>
+__device__ __forceinline__ void radix_cut(uint64_t *keys, uint32_t &cnt, uint32_t *hist, uint32_t *ctl, uint32_t k, int tid) {
+    constexpr int VPT = SEL_CAP / THREADS;
+    const uint32_t n = cnt;                                          // stable: the caller passed a barrier
+    uint64_t v[VPT];
+    uint32_t u[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t i = tid + e * THREADS;
+        v[e] = i < n ? keys[i] : KEY_INF;
+        u[e] = (uint32_t)(v[e] >> 32);
+    }
+    const uint32_t prefix = radix_kth<THREADS, VPT>(u, n, k, hist, ctl, tid);    // barriers inside: every key is in registers by now
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VPT; ++e)
+        if (tid + e * THREADS < n && u[e] <= prefix) keys[atomicAdd(&cnt, 1u)] = v[e];
+    __syncthreads();
+    const uint32_t m = cnt;
+    uint32_t n_sort = 64;
+    while (n_sort < m) n_sort <<= 1;
+    for (uint32_t i = m + tid; i < n_sort; i += THREADS) keys[i] = KEY_INF;     // the sort's padding
+    __syncthreads();
 }
 
 // One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
@@ -1146,6 +1188,12 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
         return;
     }
     // sort, keep k, carry or emit (a merge usually holds far fewer than SEL_CAP keys: sort only what is there)
+    if (merge && cnt > k) {                                     // workgroup-uniform (cnt is stable: a barrier follows every add)
+        uint32_t with = 64, without = 64;
+        while (with < k) with <<= 1;
+        while (without < cnt) without <<= 1;
+        if (with < without) radix_cut<THREADS>(keys, cnt, hist, ctl, k, tid);
+    }
     uint32_t n_sort = 64;
     while (n_sort < cnt) n_sort <<= 1;                          // cnt is stable: the scan ends with a barrier
     bitonic_sort<THREADS>(keys, tid, n_sort);

@@ -367,6 +367,31 @@ def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
         assert np.allclose(got16[0], Dr, rtol=RTOL, atol=0) and (np.sort(got16[1], axis=1) == np.sort(Ir, axis=1)).mean() > 0.99
 
 
+def test_exact16_dense_survivors_and_far_thresholds():
+    """bf16 tiles under stress: base rows ordered by DEcreasing distance (every streamed row passes the filter: the verdict words are
+    worked off in several rounds per flush, the candidate lists overflow into the exact rescan), and queries whose k-th distance lies
+    far above their own norm (threshold term R below -2^22: the conservative-margin branch of the ninth k-step)"""
+    import prefhetch_amd as pf
+    nb, nq, k, d = 40000, 130, 100, 128
+    m = (np.arange(nb)[::-1] * 129 // nb)                           # row i has m(i) entries of 2: its distance to a small query falls with i
+    xb = (np.arange(d)[None, :] < m[:, None]).astype(np.float32) * 2.0
+    rng = np.random.default_rng(11)
+    xq = rng.integers(0, 2, (nq, d)).astype(np.float32)
+    active, got16, got32 = _search_both(pf, xb, xq, k)
+    assert active
+    assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
+    Dr, Ir = oracle.flat_l2_search(xb, xq[:8], k)
+    assert (got16[1][:8] == Ir).all() and (got16[0][:8] == Dr).all()
+    # far thresholds: the base sits at +-256 in every coordinate, some queries at the origin / at the opposite corner
+    xb = (rng.integers(0, 2, (20000, d)) * 512 - 256).astype(np.float32)
+    xq = np.zeros((nq, d), np.float32)
+    xq[1::3] = -256.0
+    xq[2::3] = rng.integers(-256, 257, (len(xq[2::3]), d)).astype(np.float32)
+    active, got16, got32 = _search_both(pf, xb, xq, k)
+    assert active
+    assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
+
+
 def test_exact16_path_refuses_inexact_data():
     """one value outside the exactly-representable set switches the path off: a fraction, a large integer, a huge d"""
     import prefhetch_amd as pf
