@@ -561,6 +561,9 @@ struct Pend16 {
 // then sixteen lanes per survivor recompute the dot product from the two 16-bit rows and the group's first lane writes the
 // key.  A list too small for everything (dense early chunks) is worked off in rounds: the words not yet decoded stay in
 // the registers.  Barriers inside: call from all threads.
+#ifndef PF_FLUSH_U
+#define PF_FLUSH_U 4
+#endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn) {
@@ -598,7 +601,7 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
         const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
         // U survivors per group and pass: their rows are requested first, and in the first pass the per-row reservations (a
         // returning global atomic per row with survivors) travel at the same time -- one round trip to memory, not two
-        constexpr int U = 4;
+        constexpr int U = PF_FLUSH_U;
         const uint32_t g = (uint32_t)tid / L, l = (uint32_t)tid % L;
         for (uint32_t e0 = 0; e0 < n; e0 += G * U) {
             u32x4 va[U], vb[U];
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         }
     }
 #ifdef PF_FLAT_STAMPS
-    const bool fs_on = FILTER && p.nb_count == 524288 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
+    const bool fs_on = FILTER && p.nb_count >= 400000 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
 #endif
     // MT tiles between two flushes: their verdict words stay in registers (a 16-register vector written through a wave-uniform
     // index: the tile loop stays rolled -- unrolled MT times it ran out of registers, and a single scratch reload inside the
@@ -1271,10 +1274,6 @@ struct pf_flat {
 namespace {
 
 constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
-#ifndef PF_MAX_CHUNK
-#define PF_MAX_CHUNK 524288
-#endif
-constexpr size_t MAX_CHUNK = PF_MAX_CHUNK; // largest streaming chunk (bounds the cost of one overflow rescan)
 
 struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_qbad, total; };
 
@@ -1493,21 +1492,45 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     if (boot) launch_tile(false, boot);
     a.nb_first = 0; a.nb_count = boot; a.mode = 0; a.first = 1; a.last = boot == f->nb;
     launch_select();
-    // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a quarter of
+    // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a fraction 1/div of
     // the candidate capacity
+    static const double growth_div = getenv("PF_FLAT_GROWTH_DIV") ? atof(getenv("PF_FLAT_GROWTH_DIV")) : 0.0;   // experiments
     size_t pos = boot;
+    // Batches: rows_seen may grow by at most g_max = 1 + cap / (div * k) per chunk.  Taking g_max every time ends in a short
+    // last chunk that still costs a launch and a merge; instead the number of chunks n is the smallest that g_max allows and
+    // all of them grow by the same ratio (nb / boot)^(1/n) -- 1M rows after 8192: four chunks of ratio 3.3 at div = 3 carry
+    // the survivors per chunk that five greedy ones at div = 4 carried.
+    double ratio = 0.0;
+    int n_chunks = 0, chunk_no = 0;
+    if (geo == 2 && f->nb > boot) {
+        const double div = growth_div > 0.0 ? growth_div : 3.0, g_max = 1.0 + (double)w.cap / (div * (double)k), span = (double)f->nb / (double)boot;
+        n_chunks = (int)ceil(log(span) / log(g_max) - 1e-9);
+        if (n_chunks < 1) n_chunks = 1;
+        ratio = pow(span, 1.0 / n_chunks);
+    }
     while (pos < f->nb) {
-        static const size_t growth_div = getenv("PF_FLAT_GROWTH_DIV") ? (size_t)atoi(getenv("PF_FLAT_GROWTH_DIV")) : 4;   // experiments
-        size_t chunk = pos * w.cap / (growth_div * (size_t)k);
-        chunk = chunk / 256 * 256;
-        if (chunk < 4096) chunk = 4096;
-        if (chunk > MAX_CHUNK && geo == 2) chunk = MAX_CHUNK;       // few queries: fewer, longer launches (each one has a ramp and a merge)
-        // whole rounds of resident workgroups: a chunk that fills the device 1.2 times takes as long as one that fills it twice
-        const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
-        if (chunk > round_cols) chunk = chunk / round_cols * round_cols;
-        if (chunk > f->nb - pos) chunk = f->nb - pos;
-        // a short tail is not worth a launch and a merge of its own (the 4x margin on the candidate capacity absorbs it)
-        if (geo != 2 && f->nb - pos - chunk < chunk / 2) chunk = f->nb - pos;
+        size_t chunk;
+        if (geo == 2) {
+            ++chunk_no;
+            const double end = (double)boot * pow(ratio, chunk_no);
+            chunk = chunk_no >= n_chunks || end >= (double)f->nb ? f->nb - pos : ((size_t)end - pos) / 1024 * 1024;
+            if (chunk < 4096) chunk = 4096;
+            // whole rounds of resident workgroups: the short early chunks take as long as their rounds, however full the last one is
+            const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
+            if (chunk > round_cols && chunk < f->nb - pos) chunk = (chunk + round_cols / 2) / round_cols * round_cols;
+            if (chunk > f->nb - pos || f->nb - pos - chunk < 4096) chunk = f->nb - pos;
+        } else {
+            const double div = growth_div > 0.0 ? growth_div : 4.0;
+            chunk = (size_t)((double)pos * (double)w.cap / (div * (double)k));
+            chunk = chunk / 256 * 256;
+            if (chunk < 4096) chunk = 4096;
+            // whole rounds of resident workgroups: a chunk that fills the device 1.2 times takes as long as one that fills it twice
+            const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
+            if (chunk > round_cols) chunk = chunk / round_cols * round_cols;
+            if (chunk > f->nb - pos) chunk = f->nb - pos;
+            // a short tail is not worth a launch and a merge of its own (the 4x margin on the candidate capacity absorbs it)
+            if (f->nb - pos - chunk < chunk / 2) chunk = f->nb - pos;
+        }
         t.nb_first = pos; t.nb_count = chunk;
         launch_tile(true, chunk);
         a.nb_first = pos; a.nb_count = chunk; a.mode = 1; a.first = 0; a.last = pos + chunk == f->nb;
