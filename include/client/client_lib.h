@@ -19,7 +19,7 @@
 #include "client_server_utils.h"
 
 namespace wire { struct Transport; }
-namespace bfv { class Context; class Encryptor; class Decryptor; }
+namespace bfv { class Context; class Encryptor; class Decryptor; class KeyGenerator; }
 
 const std::string server_addr = "http://localhost:8080/";     // reference :7 (used by HTTP transports)
 
@@ -74,6 +74,15 @@ void compute_nearest_precise_vectors(const PreciseScores &precise_scores, const 
 
 // round 4: the K best vectors themselves (reference :64-69)
 void get_precise_vectors_pir(const PreciseRanking &nearest_precise_vectors, ResultVectors &query_results, ResultIds &query_results_idx);
+
+// round 4 with the ids kept private (include/client/pir.h; routes "pir-layout" and "precise-vector-pir-private"): one BFV
+// ciphertext per wanted row goes up, one comes back; the rows equal get_precise_vectors_pir's bit for bit.  `ctx` =
+// bfv::Params::seal_default(8192, 65537); the Galois keys of the expansion are generated here and sent with the first request.
+// Only the first `results_per_query` (<= K) rows of every query are fetched (a retrieval costs the server an expansion of
+// 2^levels key switches); the others are left untouched.
+void get_precise_vectors_pir_private(const PreciseRanking &nearest_precise_vectors, const bfv::Context &ctx, bfv::KeyGenerator &keygen,
+                                     bfv::Encryptor &encryptor, bfv::Decryptor &decryptor, ResultVectors &query_results,
+                                     ResultIds &query_results_idx, size_t results_per_query = (size_t)K);
 
 // Recall@{1,10,100} and MRR@{1,10,100} exactly as the reference counts them (client_lib.cpp:243-337): ground-truth
 // neighbour j < K of query i is a hit at the position k < K where it appears in the observed results; recall@R counts

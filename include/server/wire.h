@@ -71,6 +71,11 @@ std::string handle_coarse_search(const Server &server, const std::string &body);
 std::string handle_precise_search(const Server &server, const std::string &body);
 std::string handle_precise_vector_pir(Server &server, const std::string &body);
 std::string handle_precise_search_encrypted(const Server &server, const std::string &body);
+// private row retrieval (include/client/pir.h): {"rows", "levels", "ringDegree", "plainModulus"}; and
+// {"count": n, "queryCiphertexts": base64 [n][2][4][8192], "galoisKeys": base64 [levels][4][2][5][8192] (first request; kept for
+// the following ones)} -> {"replyCiphertexts": base64 [n][2][4][8192]}
+std::string handle_pir_layout(const Server &server);
+std::string handle_precise_vector_pir_private(const Server &server, const std::string &body);
 // RFC 4648 base64 of raw bytes (ciphertext payloads)
 std::string base64_encode(const void *data, size_t bytes);
 std::vector<uint8_t> base64_decode(const std::string &text);      // ParseError on malformed input

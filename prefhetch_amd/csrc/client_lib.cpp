@@ -9,6 +9,7 @@
 #include <stdexcept>
 
 #include "../../include/client/bfv.h"
+#include "../../include/client/pir.h"
 #include "../../include/prefhetch_hip.h"
 #include "../../include/server/wire.h"
 
@@ -274,6 +275,53 @@ void get_precise_vectors_pir(const std::array<std::array<DistanceIndexData, COAR
     for (size_t i = 0; i < (size_t)NQUERY; ++i)
         for (size_t j = 0; j < (size_t)K; ++j)
             for (size_t k = 0; k < (size_t)PRECISE_VECTOR_DIMENSIONS; ++k) query_results[i][j][k] = rows.at(i).at(j).at(k).as_float();
+}
+
+void get_precise_vectors_pir_private(const PreciseRanking &nearest_precise_vectors, const bfv::Context &ctx, bfv::KeyGenerator &keygen,
+                                     bfv::Encryptor &encryptor, bfv::Decryptor &decryptor, ResultVectors &query_results,
+                                     ResultIds &query_results_idx, size_t results_per_query) {
+    constexpr size_t D = (size_t)PRECISE_VECTOR_DIMENSIONS, NQ = (size_t)NQUERY;
+    if (results_per_query > (size_t)K) throw std::invalid_argument("private retrieval: at most K rows per query");
+    const wire::Json lay_json = wire::parse(transport().post("pir-layout", "{}"));
+    const pir::Layout lay = pir::Layout::make(ctx.N(), (uint32_t)D, (size_t)lay_json.at("rows").as_int());
+    if ((int64_t)lay.levels != lay_json.at("levels").as_int() || (int64_t)ctx.N() != lay_json.at("ringDegree").as_int() ||
+        (int64_t)ctx.t() != lay_json.at("plainModulus").as_int())
+        throw std::invalid_argument("private retrieval: the server packs its rows for other parameters");
+    const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, key_words = L * 2 * (L + 1) * N;
+    for (size_t i = 0; i < NQ; ++i)
+        for (size_t j = 0; j < (size_t)K; ++j) query_results_idx[i][j] = nearest_precise_vectors[i][j].idx;
+    // Galois keys of the expansion rounds, in pf_key_switch's layout
+    std::vector<uint64_t> keys((size_t)lay.levels * key_words);
+    {
+        size_t j = 0;
+        for (uint32_t g : pir::galois_elements((uint32_t)N, lay.levels)) {
+            const bfv::SwitchKey gk = keygen.create_galois_key(g);
+            gk.ksk.download(keys.data() + j++ * key_words, key_words);
+        }
+    }
+    bool keys_sent = false;
+    std::vector<uint64_t> plain(results_per_query * N), words(results_per_query * per), back;
+    for (size_t i = 0; i < NQ; ++i) {                                                 // one request per query
+        if (results_per_query == 0) break;
+        for (size_t j = 0; j < results_per_query; ++j) pir::encode_query(lay, ctx.t(), (size_t)query_results_idx[i][j], plain.data() + j * N);
+        bfv::Ciphertexts qct;
+        encryptor.encrypt(plain.data(), results_per_query, qct);
+        qct.data.download(words.data(), words.size());
+        std::string body = "{\"count\":" + std::to_string(results_per_query) + ",\"queryCiphertexts\":\"" + wire::base64_encode(words.data(), words.size() * 8) + "\"";
+        if (!keys_sent) { body += ",\"galoisKeys\":\"" + wire::base64_encode(keys.data(), keys.size() * 8) + "\""; keys_sent = true; }
+        body.push_back('}');
+        const wire::Json resp = wire::parse(transport().post("precise-vector-pir-private", body));
+        const wire::Json &blob = resp.at("replyCiphertexts");
+        if (blob.kind != wire::Json::String) throw wire::TypeError("replyCiphertexts must be a base64 string");
+        const std::vector<uint8_t> raw = wire::base64_decode(blob.s);
+        if (raw.size() != results_per_query * per * 8) throw std::out_of_range("replyCiphertexts has the wrong size");
+        bfv::Ciphertexts rct;
+        rct.count = results_per_query;
+        rct.data = bfv::DeviceWords(ctx.params().device, results_per_query * per);
+        rct.data.upload(reinterpret_cast<const uint64_t *>(raw.data()), results_per_query * per);
+        decryptor.decrypt(rct, back);
+        for (size_t j = 0; j < results_per_query; ++j) pir::decode_row(lay, back.data() + j * N, (size_t)query_results_idx[i][j], query_results[i][j].data());
+    }
 }
 
 RecallStats compute_recall_stats(const std::array<std::array<faiss_idx_t, K>, NQUERY> &observed, const std::vector<int> &ground_truth,

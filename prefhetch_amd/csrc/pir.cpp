@@ -1,0 +1,153 @@
+// pir.cpp -- see include/client/pir.h.  Host C++ over the C ABI (prefhetch_hip.h) and the BFV helpers (bfv.h): every
+// ring operation runs on the GPU -- pf_ct_pt_mul (monomial products of the expansion, the database products),
+// pf_apply_galois + pf_key_switch (bfv::apply_galois), pf_poly_add / pf_poly_sub, pf_ntt_forward / pf_ntt_inverse.
+#include "../../include/client/pir.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/prefhetch_hip.h"
+
+namespace pir {
+namespace {
+
+void check(pf_status st, const char *what) {
+    if (st != PF_OK) throw std::runtime_error(std::string("pir: ") + what + ": " + pf_status_str(st) + " (" + pf_last_error() + ")");
+}
+
+uint64_t powmod(uint64_t a, uint64_t e, uint64_t m) {
+    unsigned __int128 r = 1 % m, b = a % m;
+    for (; e; e >>= 1, b = b * b % m)
+        if (e & 1) r = r * b % m;
+    return (uint64_t)r;
+}
+
+// inverse of 2^levels modulo an odd t (t need not be prime): ((t + 1) / 2)^levels
+uint64_t inv_pow2(uint32_t levels, uint64_t t) {
+    if (!(t & 1)) throw std::invalid_argument("pir: the plaintext modulus must be odd (2^levels has to be invertible)");
+    return powmod((t + 1) / 2, levels, t);
+}
+
+}  // namespace
+
+Layout Layout::make(uint32_t N, uint32_t d, size_t n_rows) {
+    Layout l;
+    if (d == 0 || 2 * (size_t)d > N) throw std::invalid_argument("pir: a row (2 coefficients per value) must fit one polynomial");
+    l.N = N; l.d = d; l.n_rows = n_rows;
+    l.rows_per_poly = N / (2 * d);
+    l.n_polys = (n_rows + l.rows_per_poly - 1) / l.rows_per_poly;
+    if (l.n_polys == 0) l.n_polys = 1;
+    while ((size_t{1} << l.levels) < l.n_polys) ++l.levels;
+    if ((size_t{1} << l.levels) > N) throw std::invalid_argument("pir: more than N polynomials need a second query dimension (not built)");
+    return l;
+}
+
+Database::Database(const bfv::Context &ctx, const float *rows, size_t n_rows, uint32_t d) : m_Layout(Layout::make(ctx.N(), d, n_rows)) {
+    if (ctx.t() <= 65536) throw std::invalid_argument("pir: plaintext modulus must exceed 2^16 (two 16-bit halves per value)");
+    const size_t N = ctx.N(), L = ctx.L(), P = m_Layout.n_polys;
+    // coefficients are below t < every q_l: the lift to the ciphertext moduli repeats the value in each limb
+    std::vector<uint64_t> host(P * L * N, 0);
+    for (size_t r = 0; r < n_rows; ++r) {
+        uint64_t *poly = host.data() + m_Layout.poly_of(r) * L * N;
+        const size_t c0 = (size_t)m_Layout.slot_of(r) * 2 * d;
+        for (uint32_t i = 0; i < d; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, rows + r * d + i, 4);
+            for (size_t l = 0; l < L; ++l) {
+                poly[l * N + c0 + 2 * i] = bits & 0xFFFFu;
+                poly[l * N + c0 + 2 * i + 1] = bits >> 16;
+            }
+        }
+    }
+    m_Ntt = bfv::DeviceWords(ctx.params().device, P * L * N);
+    m_Ntt.upload(host.data(), host.size());
+    check(pf_ntt_forward(ctx.ring(), m_Ntt.ptr(), P * L, nullptr), "pf_ntt_forward");
+    check(pf_stream_synchronize(ctx.params().device, nullptr), "sync");
+}
+
+std::vector<uint32_t> galois_elements(uint32_t N, uint32_t levels) {
+    std::vector<uint32_t> g(levels);
+    for (uint32_t j = 0; j < levels; ++j) g[j] = (N >> j) + 1;
+    return g;
+}
+
+void expand(const bfv::Context &ctx, const bfv::Ciphertexts &query_one, const std::vector<bfv::SwitchKey> &keys, uint32_t levels,
+            bfv::Ciphertexts &out) {
+    if (query_one.count != 1) throw std::invalid_argument("pir::expand: one query ciphertext at a time");
+    if (keys.size() < levels) throw std::invalid_argument("pir::expand: a Galois key per round is needed");
+    const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, n_out = size_t{1} << levels;
+    const int dev = ctx.params().device;
+    const std::vector<uint32_t> elts = galois_elements(ctx.N(), levels);
+    out.count = n_out;
+    if (out.data.words() < n_out * per) out.data = bfv::DeviceWords(dev, n_out * per);
+    check(pf_memcpy_d2d(dev, out.data.ptr(), query_one.data.ptr(), per * 8, nullptr), "d2d");
+    // the monomials X^(-2^j) = -X^(N - 2^j) of all rounds, as NTT-form "plaintexts" of pf_ct_pt_mul
+    std::vector<uint64_t> mono(levels * L * N, 0);
+    for (uint32_t j = 0; j < levels; ++j)
+        for (size_t l = 0; l < L; ++l) mono[(j * L + l) * N + (N - (size_t{1} << j))] = ctx.params().moduli[l] - 1;
+    bfv::DeviceWords d_mono(dev, mono.size() ? mono.size() : 1);
+    if (levels) {
+        d_mono.upload(mono.data(), mono.size());
+        check(pf_ntt_forward(ctx.ring(), d_mono.ptr(), (size_t)levels * L, nullptr), "pf_ntt_forward");
+    }
+    bfv::Ciphertexts cur, rot;
+    for (uint32_t j = 0; j < levels; ++j) {
+        if (keys[j].galois_elt != elts[j]) throw std::invalid_argument("pir::expand: keys[j] must be the Galois key of N / 2^j + 1");
+        const size_t B = size_t{1} << j;
+        // the first B ciphertexts of `out` are this round's inputs
+        cur.count = B;
+        if (cur.data.words() < B * per) cur.data = bfv::DeviceWords(dev, B * per);
+        check(pf_memcpy_d2d(dev, cur.data.ptr(), out.data.ptr(), B * per * 8, nullptr), "d2d");
+        bfv::apply_galois(ctx, cur, keys[j], rot);                                       // s_j(c): automorphism + key switch, B at once
+        uint64_t *lo = out.data.ptr(), *hi = out.data.ptr() + B * per;
+        check(pf_poly_sub(ctx.ring(), cur.data.ptr(), rot.data.ptr(), hi, B * 2 * L, nullptr), "pf_poly_sub");          // c - s_j(c)
+        check(pf_poly_add(ctx.ring(), cur.data.ptr(), rot.data.ptr(), lo, B * 2 * L, nullptr), "pf_poly_add");          // c + s_j(c)
+        check(pf_ct_pt_mul(ctx.ring(), hi, d_mono.ptr() + (size_t)j * L * N, 1, hi, B, 0, nullptr), "pf_ct_pt_mul");   // * X^(-2^j)
+    }
+    check(pf_stream_synchronize(dev, nullptr), "sync");
+}
+
+void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts &query, const std::vector<bfv::SwitchKey> &keys,
+            bfv::Ciphertexts &reply) {
+    const Layout &lay = db.layout();
+    const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, P = lay.n_polys;
+    const int dev = ctx.params().device;
+    reply.count = query.count;
+    if (query.count == 0) return;
+    if (reply.data.words() < query.count * per) reply.data = bfv::DeviceWords(dev, query.count * per);
+    bfv::Ciphertexts one, sel;
+    one.count = 1;
+    one.data = bfv::DeviceWords(dev, per);
+    bfv::DeviceWords prod(dev, P * per);
+    for (size_t q = 0; q < query.count; ++q) {
+        check(pf_memcpy_d2d(dev, one.data.ptr(), query.data.ptr() + q * per, per * 8, nullptr), "d2d");
+        expand(ctx, one, keys, lay.levels, sel);
+        // products in NTT form, summed there by halving (one launch per halving), one inverse transform at the end
+        check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt(), P, prod.ptr(), P, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
+        for (size_t n = P; n > 1;) {
+            const size_t half = n / 2, keep = n - half;                                  // fold the last `half` onto the first `half`
+            check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
+            n = keep;
+        }
+        uint64_t *out = reply.data.ptr() + q * per;
+        check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), out, 2 * L, nullptr), "pf_ntt_inverse_to");
+    }
+    check(pf_stream_synchronize(dev, nullptr), "sync");
+}
+
+void encode_query(const Layout &lay, uint64_t t, size_t row, uint64_t *plain_out) {
+    if (row >= lay.n_rows) throw std::out_of_range("pir::encode_query: no such row");
+    std::memset(plain_out, 0, (size_t)lay.N * 8);
+    plain_out[lay.poly_of(row)] = inv_pow2(lay.levels, t);
+}
+
+void decode_row(const Layout &lay, const uint64_t *plain, size_t row, float *out) {
+    const size_t c0 = (size_t)lay.slot_of(row) * 2 * lay.d;
+    for (uint32_t i = 0; i < lay.d; ++i) {
+        const uint32_t bits = (uint32_t)(plain[c0 + 2 * i] & 0xFFFFu) | ((uint32_t)(plain[c0 + 2 * i + 1] & 0xFFFFu) << 16);
+        std::memcpy(out + i, &bits, 4);
+    }
+}
+
+}  // namespace pir

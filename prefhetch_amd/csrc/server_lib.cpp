@@ -16,6 +16,8 @@
 
 #include "../../include/prefhetch_hip.h"
 #include "../../include/server/http.h"
+#include "../../include/client/pir.h"
+#include <memory>
 #include <cstdlib>
 
 #ifdef PREFHETCH_WITH_DROGON
@@ -112,6 +114,14 @@ std::vector<float> residual_slice(const float *x, size_t n, const std::vector<in
 
 }  // namespace
 
+// private row retrieval (include/client/pir.h): BFV context with a special prime + the packed base, built on first use
+struct PirState {
+    bfv::Context ctx;
+    pir::Database db;
+    PirState(int device, const float *rows, size_t n_rows)
+        : ctx(bfv::Params::seal_default(Server::ENC_RING_DEGREE, Server::PIR_PLAIN_MODULUS, device)), db(ctx, rows, n_rows, static_cast<uint32_t>(PRECISE_VECTOR_DIMENSIONS)) {}
+};
+
 struct Server::Impl {
     int device = 0;
     pf_flat *base = nullptr;        // NBASE x 128 fp32 in HBM (reference: m_DatasetBase)
@@ -123,6 +133,8 @@ struct Server::Impl {
     // the reference's handlers run on one Drogon loop thread; this lock makes concurrent const calls safe anyway
     mutable std::mutex lock;
     mutable DevBuf d_query, d_ids, d_out, d_out2, d_pt;
+    mutable std::unique_ptr<PirState> pir;
+    PirState &pir_state() const;
 
     ~Impl() {
         reset();
@@ -132,6 +144,7 @@ struct Server::Impl {
         if (centroids) pf_flat_destroy(centroids);
         if (ivfpq) pf_ivfpq_destroy(ivfpq);
         if (ring) pf_ctx_destroy(ring);
+        pir.reset();
         base = nullptr; centroids = nullptr; ivfpq = nullptr; ring = nullptr;
         d_query.release(); d_ids.release(); d_out.release(); d_out2.release(); d_pt.release();   // they belong to the old device
     }
@@ -408,6 +421,42 @@ void Server::preciseVectorPIR(const std::array<std::array<faiss_idx_t, K>, NQUER
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }
 
+size_t Server::pirRows() const {
+    std::lock_guard<std::mutex> g(m_Impl->lock);
+    m_Impl->require_ready();
+    return m_Impl->nb;
+}
+
+uint32_t Server::pirLevels() const {
+    std::lock_guard<std::mutex> g(m_Impl->lock);
+    m_Impl->require_ready();
+    return pir::Layout::make(ENC_RING_DEGREE, static_cast<uint32_t>(PRECISE_VECTOR_DIMENSIONS), m_Impl->nb).levels;
+}
+
+void Server::preciseVectorPIRPrivateHost(const uint64_t *query_ct_host, size_t count, const uint64_t *galois_keys_host, uint64_t *reply_ct_host) const {
+    if (count == 0) return;
+    if (!query_ct_host || !galois_keys_host || !reply_ct_host) throw std::invalid_argument("preciseVectorPIRPrivateHost: null buffer");
+    const Impl &im = *m_Impl;
+    std::lock_guard<std::mutex> g(im.lock);
+    im.require_ready();
+    PirState &ps = im.pir_state();
+    const size_t N = ENC_RING_DEGREE, D = ENC_LIMBS, per = 2 * D * N, key_words = D * 2 * (D + 1) * N;
+    const uint32_t levels = ps.db.layout().levels;
+    const std::vector<uint32_t> elts = pir::galois_elements(ENC_RING_DEGREE, levels);
+    std::vector<bfv::SwitchKey> keys(levels);
+    for (uint32_t j = 0; j < levels; ++j) {
+        keys[j].ksk = bfv::DeviceWords(im.device, key_words);
+        keys[j].ksk.upload(galois_keys_host + j * key_words, key_words);
+        keys[j].galois_elt = elts[j];
+    }
+    bfv::Ciphertexts query, reply;
+    query.count = count;
+    query.data = bfv::DeviceWords(im.device, count * per);
+    query.data.upload(query_ct_host, count * per);
+    pir::answer(ps.ctx, ps.db, query, keys, reply);
+    reply.data.download(reply_ct_host, count * per);
+}
+
 void Server::nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,
                               std::array<std::array<faiss::idx_t, NPROBE>, NQUERY> &nearest_centroid_idx,
                               std::array<std::array<float, NPROBE>, NQUERY> &nearest_centroid_dist) const {
@@ -423,4 +472,25 @@ void Server::nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_
     check(pf_memcpy_d2h(im.device, nearest_centroid_dist.data(), im.d_out.ptr, sizeof nearest_centroid_dist, nullptr), "d2h");
     check(pf_memcpy_d2h(im.device, nearest_centroid_idx.data(), im.d_out2.ptr, sizeof nearest_centroid_idx, nullptr), "d2h");
     check(pf_stream_synchronize(im.device, nullptr), "sync");
+}
+
+
+// caller holds the lock
+PirState &Server::Impl::pir_state() const {
+    const Impl &im = *this;
+    if (!im.pir) {
+        // the base lives in HBM (pf_flat): one gather brings the rows back for packing
+        std::vector<int64_t> ids(im.nb);
+        for (size_t i = 0; i < im.nb; ++i) ids[i] = static_cast<int64_t>(i);
+        std::vector<float> rows(im.nb * kD);
+        DevBuf d_ids, d_rows;
+        d_ids.reserve(im.device, ids.size() * 8);
+        d_rows.reserve(im.device, rows.size() * sizeof(float));
+        check(pf_memcpy_h2d(im.device, d_ids.ptr, ids.data(), ids.size() * 8, nullptr), "h2d");
+        check(pf_gather_rows(im.base, static_cast<const int64_t *>(d_ids.ptr), im.nb, static_cast<float *>(d_rows.ptr), nullptr), "pf_gather_rows");
+        check(pf_memcpy_d2h(im.device, rows.data(), d_rows.ptr, rows.size() * sizeof(float), nullptr), "d2h");
+        check(pf_stream_synchronize(im.device, nullptr), "sync");
+        im.pir = std::make_unique<PirState>(im.device, rows.data(), im.nb);
+    }
+    return *im.pir;
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <memory>
 
 namespace wire {
@@ -399,12 +400,56 @@ std::string handle_precise_search_encrypted(const Server &server, const std::str
     return resp;
 }
 
+// ---- private row retrieval (include/client/pir.h) -------------------------------------------------------------
+std::string handle_pir_layout(const Server &server) {
+    return "{\"rows\":" + std::to_string(server.pirRows()) + ",\"levels\":" + std::to_string(server.pirLevels()) +
+           ",\"ringDegree\":" + std::to_string(Server::ENC_RING_DEGREE) + ",\"plainModulus\":" + std::to_string(Server::PIR_PLAIN_MODULUS) + "}";
+}
+
+std::string handle_precise_vector_pir_private(const Server &server, const std::string &body) {
+    // The Galois keys of the expansion (tens of megabytes) are sent once and kept for the requests that follow without
+    // "galoisKeys": one client session per server process, like the reference's single-client demo.
+    static std::mutex key_lock;
+    static std::vector<uint64_t> session_keys;
+    const Json req = parse(body);
+    const size_t count = (size_t)req.at("count").as_int();
+    constexpr size_t per = 2 * (size_t)Server::ENC_LIMBS * Server::ENC_RING_DEGREE;
+    const size_t key_words = (size_t)server.pirLevels() * Server::ENC_LIMBS * 2 * (Server::ENC_LIMBS + 1) * Server::ENC_RING_DEGREE;
+    std::vector<uint64_t> keys;
+    {
+        std::lock_guard<std::mutex> g(key_lock);
+        const Json *k = nullptr;
+        if (req.kind == Json::Object)
+            for (const auto &kv : req.obj)
+                if (kv.first == "galoisKeys") k = &kv.second;
+        if (k) {
+            if (k->kind != Json::String) throw TypeError("galoisKeys must be a base64 string");
+            const std::vector<uint8_t> raw = base64_decode(k->s);
+            if (raw.size() != key_words * 8) throw std::out_of_range("galoisKeys: expected " + std::to_string(key_words * 8) + " bytes, got " + std::to_string(raw.size()));
+            session_keys.resize(key_words);
+            std::memcpy(session_keys.data(), raw.data(), raw.size());
+        }
+        if (session_keys.size() != key_words) throw std::out_of_range("precise-vector-pir-private: no Galois keys in this request and none kept from an earlier one");
+        keys = session_keys;
+    }
+    const Json &blob = req.at("queryCiphertexts");
+    if (blob.kind != Json::String) throw TypeError("queryCiphertexts must be a base64 string");
+    const std::vector<uint8_t> raw = base64_decode(blob.s);
+    if (raw.size() != count * per * 8) throw std::out_of_range("queryCiphertexts: expected " + std::to_string(count * per * 8) + " bytes, got " + std::to_string(raw.size()));
+    std::vector<uint64_t> in(count * per), out(count * per);
+    std::memcpy(in.data(), raw.data(), raw.size());
+    server.preciseVectorPIRPrivateHost(in.data(), count, keys.data(), out.data());
+    return "{\"replyCiphertexts\":\"" + base64_encode(out.data(), out.size() * 8) + "\"}";
+}
+
 std::string handle(Server &server, const std::string &route, const std::string &body) {
     if (route == "query") return handle_query(server);
     if (route == "coarsesearch") return handle_coarse_search(server, body);
     if (route == "precisesearch") return handle_precise_search(server, body);
     if (route == "precise-vector-pir") return handle_precise_vector_pir(server, body);
     if (route == "precisesearch-encrypted") return handle_precise_search_encrypted(server, body);
+    if (route == "pir-layout") return handle_pir_layout(server);
+    if (route == "precise-vector-pir-private") return handle_precise_vector_pir_private(server, body);
     throw std::out_of_range("no such route: " + route);
 }
 

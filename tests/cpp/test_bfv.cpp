@@ -2,13 +2,16 @@
 // (Server::preciseSearchEncrypted) on a real MI355X: encrypt -> server -> decrypt must reproduce the plaintext
 // protocol's numbers exactly, with noise budget to spare.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <vector>
 
 #include "../../include/client/bfv.h"
+#include "../../include/client/pir.h"
 #include "../../include/client/client_lib.h"
 #include "../../include/server/wire.h"
 #include "../../include/prefhetch_hip.h"
@@ -238,7 +241,85 @@ int main() {
         bool threw = false;
         try { link.post("precisesearch-encrypted", "{\"nearestCoarseVectorIndexes\": [], \"queryCiphertexts\": \"AAAA\"}"); } catch (const std::out_of_range &) { threw = true; }
         EXPECT(threw);
+        // ---- 3b. round 4 with private ids: the rows come back equal to the plain copy's, bit for bit -------------------
+        {
+            PreciseRanking nearest;
+            for (size_t i = 0; i < static_cast<size_t>(NQUERY); ++i)
+                for (size_t j = 0; j < static_cast<size_t>(COARSE_PROBE); ++j) nearest[i][j] = DistanceIndexData{clear_scores[i][j], ids[i][(j * 7 + i) % COARSE_PROBE]};
+            auto plain_rows = std::make_unique<ResultVectors>();
+            auto private_rows = std::make_unique<ResultVectors>();
+            ResultIds plain_ids, private_ids;
+            get_precise_vectors_pir(nearest, *plain_rows, plain_ids);                   // the reference's round 4: ids in the clear
+            bfv::Context pctx(bfv::Params::seal_default(8192, Server::PIR_PLAIN_MODULUS));
+            bfv::KeyGenerator pkeygen(pctx, bfv::seeded_random(31));
+            bfv::PublicKey ppk = pkeygen.create_public_key();
+            bfv::Encryptor penc(pctx, ppk, bfv::seeded_random(32));
+            bfv::Decryptor pdec(pctx, pkeygen.secret_key());
+            const size_t fetch = 2, sent1 = link.bytes_sent, recv1 = link.bytes_received;
+            const auto t0 = std::chrono::steady_clock::now();
+            get_precise_vectors_pir_private(nearest, pctx, pkeygen, penc, pdec, *private_rows, private_ids, fetch);
+            const double pir_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            bool same = private_ids == plain_ids;
+            for (size_t i = 0; i < static_cast<size_t>(NQUERY); ++i)
+                for (size_t j = 0; j < fetch; ++j) same = same && std::memcmp((*private_rows)[i][j].data(), (*plain_rows)[i][j].data(), sizeof(float) * 128) == 0;
+            EXPECT(same);
+            std::printf("private retrieval over the wire format: %zu rows of %zu (levels %u), %zu request bytes (Galois keys once), %zu response bytes\n",
+                        fetch * static_cast<size_t>(NQUERY), srv->pirRows(), srv->pirLevels(), link.bytes_sent - sent1, link.bytes_received - recv1);
+            std::printf("  %.0f ms for the round (key generation, base64, %u expansion rounds of 2^j key switches and %zu products per row included)\n", pir_ms,
+                        srv->pirLevels(), (srv->pirRows() + 31) / 32);
+        }
         set_transport(nullptr);
+    }
+    // ---- 4. private row retrieval (include/client/pir.h): the id never leaves the client ----------------------------------
+    {
+        bfv::Context ctx(bfv::Params::seal_default(8192, 65537));
+        bfv::KeyGenerator keygen(ctx, bfv::seeded_random(4242));
+        bfv::PublicKey pk = keygen.create_public_key();
+        bfv::Encryptor enc(ctx, pk, bfv::seeded_random(4243));
+        bfv::Decryptor dec(ctx, keygen.secret_key());
+        const uint32_t d = 128;
+        const size_t n_rows = 1000;                                                    // 32 polynomials of 32 rows: five expansion rounds
+        std::vector<float> base(n_rows * d);
+        std::mt19937_64 rng(99);
+        for (auto &v : base) v = (float)((double)(int64_t)(rng() % 2000001) / 1000.0 - 1000.0);   // fractions, negatives: every bit of a float matters
+        base[5 * d + 3] = -0.0f; base[5 * d + 4] = 3.4e38f; base[5 * d + 5] = 1e-40f;              // signed zero, near the largest, a subnormal
+        pir::Database db(ctx, base.data(), n_rows, d);
+        const pir::Layout &lay = db.layout();
+        EXPECT(lay.rows_per_poly == 32 && lay.n_polys == 32 && lay.levels == 5);
+        std::vector<bfv::SwitchKey> keys;
+        for (uint32_t g : pir::galois_elements(ctx.N(), lay.levels)) keys.push_back(keygen.create_galois_key(g));
+        // the expansion alone: 2^levels ciphertexts, a one at the asked position and zeros elsewhere
+        {
+            std::vector<uint64_t> plain(ctx.N()), back;
+            pir::encode_query(lay, ctx.t(), 21 * 32 + 7, plain.data());                  // polynomial 21
+            bfv::Ciphertexts q, sel;
+            enc.encrypt(plain.data(), 1, q);
+            pir::expand(ctx, q, keys, lay.levels, sel);
+            dec.decrypt(sel, back);
+            bool ok = sel.count == 32;
+            for (size_t k = 0; ok && k < 32; ++k)
+                for (size_t i = 0; ok && i < ctx.N(); ++i) ok = back[k * ctx.N() + i] == (k == 21 && i == 0 ? 1u : 0u);
+            EXPECT(ok);
+            std::printf("PIR expansion: 1 -> 32 ciphertexts, noise budget %d -> %d bits\n", dec.invariant_noise_budget(q, 0), dec.invariant_noise_budget(sel, 31));
+        }
+        const size_t wanted[4] = {0, 5, 517, 999};
+        std::vector<uint64_t> plain(4 * ctx.N()), back;
+        for (size_t i = 0; i < 4; ++i) pir::encode_query(lay, ctx.t(), wanted[i], plain.data() + i * ctx.N());
+        bfv::Ciphertexts query, reply;
+        enc.encrypt(plain.data(), 4, query);
+        pir::answer(ctx, db, query, keys, reply);
+        dec.decrypt(reply, back);
+        for (size_t i = 0; i < 4; ++i) {
+            float row[128];
+            pir::decode_row(lay, back.data() + i * ctx.N(), wanted[i], row);
+            EXPECT(std::memcmp(row, base.data() + wanted[i] * d, sizeof row) == 0);     // bit for bit, -0.0f and the subnormal included
+        }
+        std::printf("PIR: 4 rows of %zu retrieved privately (1 ciphertext up, 1 down each); reply noise budget %d bits\n", n_rows,
+                    dec.invariant_noise_budget(reply, 3));
+        EXPECT(dec.invariant_noise_budget(reply, 3) > 0);
+        bool threw = false;
+        try { pir::encode_query(lay, ctx.t(), n_rows, plain.data()); } catch (const std::out_of_range &) { threw = true; }
+        EXPECT(threw);
     }
     if (fails) std::printf("test_bfv: %d FAILURES\n", fails);
     else std::printf("test_bfv: OK\n");
