@@ -182,15 +182,18 @@ pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_h
 pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 
-/* 16-bit operands for exactly-representable data.  When every value of the base matrix is an integer of magnitude <= 256
- * (checked on the device, value by value, by pf_flat_create; d = 64 or 128) the index keeps a bf16 image
- * of it, and pf_flat_search runs query tiles whose values pass the same check (again on the device, every search) through
- * the bf16 matrix instruction with fp32 accumulation: every product and every partial sum is then an integer below 2^24,
- * so the accumulator -- and with it every distance and every index -- is bit for bit what the fp32 loop returns.  Data
- * that fails the check (one value suffices) runs the fp32 loop; the caller never has to know.  SIFT, the reference's
- * dataset (8-bit values, /root/reference/include/common/client_server_utils.h:10-20), qualifies.
- * mode 1 = on where the data allows (default), 0 = fp32 operands always, -1 = query only.
- * *active_out (may be NULL): 1 if the base passed the check and the path is on. */
+/* 16-bit operands for the batch pre-filter (d = 64 or 128, more than 64 queries).  pf_flat_create keeps a bf16 image of the
+ * base (nearest-even) and checks on the device, value by value, whether it IS the base: every value an integer of magnitude
+ * <= 256 (SIFT, the reference's dataset -- 8-bit values, /root/reference/include/common/client_server_utils.h:10-20 --
+ * qualifies); query tiles are checked the same way at every search.
+ *   exact operands    every product and every partial sum is an integer below 2^24: the bf16 matrix instruction with fp32
+ *                     accumulation evaluates the distance test itself, and a survivor's distance is recomputed from the
+ *                     16-bit rows -- bit for bit the fp32 chain's number.
+ *   inexact operands  the bf16 tiles run as a CONSERVATIVE FILTER (thresholds lowered by the bound on the operands' rounding,
+ *                     2^-8 (|x|^2 + max |y|^2)); every survivor's distance is the k-ordered fp32 chain over the fp32 rows.
+ * Either way (D, I) are what the fp32-operand loop returns, bit for bit; the caller never has to know.
+ * mode 1 = on (default), 0 = fp32 operands always, -1 = query only.
+ * *active_out (may be NULL): 2 = on with an exactly representable base, 1 = on as a filter over an inexact base, 0 = off. */
 pf_status pf_flat_exact16(pf_flat *idx, int mode, int *active_out);
 
 /* pf_flat_search that also (or only: D and I may then be NULL) writes the exchange record of the multi-GPU gather,

@@ -217,12 +217,17 @@ class FlatL2:
 
     __del__ = close
 
-    def exact16(self, mode=-1):
-        """16-bit operand path for exactly-representable data (pf_flat_exact16): mode 1 on where the data allows (default),
-        0 fp32 operands always, -1 query.  Returns True when the base passed the on-device check and the path is on."""
+    def operands16(self, mode=-1):
+        """bf16 tiles of the batch pre-filter (pf_flat_exact16): mode 1 on (default), 0 fp32 operands always, -1 query.
+        Returns 2 when on with an exactly representable base (the tiles evaluate the distance test itself), 1 when on as a
+        conservative filter over an inexact base (survivors re-evaluated by the fp32 chain), 0 when off."""
         a = C.c_int()
         check(lib.pf_flat_exact16(self._h, int(mode), C.byref(a)), "pf_flat_exact16")
-        return bool(a.value)
+        return int(a.value)
+
+    def exact16(self, mode=-1):
+        """True when the bf16 tiles are on AND the base passed the on-device exactness check (operands16() == 2)."""
+        return self.operands16(mode) == 2
 
     def reserve(self, nq_max, k_max):
         check(lib.pf_flat_reserve(self._h, nq_max, k_max), "pf_flat_reserve")

@@ -26,8 +26,10 @@
 // Keys order by (distance, id), which fixes the tie order faiss leaves undefined.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <cstdlib>
 #include <string>
+#include <vector>
 #include "pf_common.hpp"
 
 namespace pf {
@@ -86,6 +88,11 @@ __device__ __forceinline__ void bf16_split3(float v, uint32_t (&piece)[3]) {
     }
 }
 constexpr uint32_t BF16_ONE = 0x3F80u, BF16_SIGN = 0x8000u;
+// nearest bf16 (ties to even) of a finite fp32: |bf16 - v| <= 2^-8 |v| (what the filter margin of the inexact path prices)
+__device__ __forceinline__ uint16_t bf16_rne(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
 constexpr uint32_t AUX16 = 8;                   // 16-bit words a base row of the image carries behind its d values (below)
 
 // row norms (fp32 fma chain in index order) + 16-bit image + eligibility.  A workgroup of 64 threads takes ROWS rows: the rows
@@ -109,7 +116,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
         const float v = src[e];
         const uint32_t r = e / d, k = e - r * d;
         tile[r * (d + 1) + k] = v;
-        if (x16) x16[(r0 + r) * pitch16 + k] = (uint16_t)(__float_as_uint(v) >> 16);      // exact when the value passes; unused otherwise
+        if (x16) x16[(r0 + r) * pitch16 + k] = bf16_rne(v);                              // exact when the value passes; nearest otherwise
         if (inexact && !bf16_exact(v)) bad |= 1u << (rows_per_flag ? ((r0 + r) / rows_per_flag - r0 / rows_per_flag) : 0);
     }
     if (bad) {                                                    // a block of <= 64 rows touches at most two flags (rows_per_flag >= 64) or one
@@ -152,6 +159,8 @@ struct TileArgs {
     // exactly-representable data (see "bf16 operands" below): 16-bit images of the queries / the base, and per 128-query
     // tile a word that is non-zero when some value of the tile is NOT exactly representable (then the fp32 loop runs)
     const uint16_t *xq16; const uint16_t *xb16; const uint32_t *q_inexact;
+    uint32_t base_exact;    // every value of the base is exactly representable in bf16
+    float bn_max;           // largest |y|^2 of the base (the inexact path's filter margin)
 };
 
 // Tile geometry: TM queries x TN base rows per workgroup of 256 threads (4 waves laid out WM x WN); a wave owns
@@ -566,7 +575,7 @@ struct Pend16 {
 #endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
-                                             uint32_t ct_base, int wm, int wn) {
+                                             uint32_t ct_base, int wm, int wn, bool approx) {
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
     const int lane = tid & 63;
@@ -599,6 +608,32 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             }
         __syncthreads();
         const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
+        if (approx) {                                                 // workgroup-uniform
+            // inexact operands: the distance of a survivor is the k-ordered fp32 chain over the fp32 rows -- what the fp32 tiles
+            // and the oracle evaluate -- one lane per survivor (the order of the additions is part of the result)
+            if (tid < 128) {
+                const uint32_t c = pd.rcnt[tid];
+                pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
+                pd.rcnt[tid] = 0;
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < n; e += 256) {
+                const uint32_t loc = pd.loc[e], id = pd.id[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
+                if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
+                const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D), *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
+                float acc = 0.f;
+#pragma unroll 4
+                for (int t = 0; t < D / 4; ++t) {
+                    const float4 a = x[t], b = y[t];
+                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                }
+                const float dist = fmaf(-2.f, acc, sA[2 * row] + p.bn[id]);
+                p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+            }
+            __syncthreads();
+            if (tid == 0) pd.n = 0;
+            continue;
+        }
         // U survivors per group and pass: their rows are requested first, and in the first pass the per-row reservations (a
         // returning global atomic per row with survivors) travel at the same time -- one round trip to memory, not two
         constexpr int U = PF_FLUSH_U;
@@ -685,7 +720,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     using GEO = GeoBatch;
     constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
-    constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
+    constexpr size_t SMEM = FILTER || 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback (unfiltered launch) borrows this LDS
     static_assert(PITCH % 32 == 16 && TN == 128 && TM == 128, "odd row pitch in 16-byte units; 128 x 128 tiles");
     __shared__ __align__(16) char smem[SMEM];
     __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
@@ -700,12 +735,19 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     }
     const uint32_t n_ct = (uint32_t)((p.nb_count + TN - 1) / TN);
     const uint32_t ct0 = grp * group, ct1 = ct0 + group < n_ct ? ct0 + group : n_ct;
-    if (p.q_inexact[qt]) {                                          // workgroup-uniform: fp32 operands for this query tile
-        for (uint32_t ct = ct0; ct < ct1; ++ct) {
-            l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
-            __syncthreads();
+    // Operands that are NOT exactly representable (the base as a whole, or this query tile; flags set on the device): the
+    // unfiltered bootstrap launch writes distances, so it runs the fp32 tile body; a filtered launch keeps the bf16 tiles as a
+    // CONSERVATIVE FILTER (row thresholds lowered by the bound on the rounding of the operands, below) and flush() evaluates
+    // the survivors with the fp32 chain.
+    const bool approx = !p.base_exact || p.q_inexact[qt];           // workgroup-uniform
+    if constexpr (!FILTER) {
+        if (approx) {
+            for (uint32_t ct = ct0; ct < ct1; ++ct) {
+                l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
+                __syncthreads();
+            }
+            return;
         }
-        return;
     }
     const size_t q0 = (size_t)qt * TM;
     const uint32_t q_valid = (uint32_t)(p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM);
@@ -766,8 +808,14 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     if constexpr (FILTER) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const float rq = stage[3 * TM + wm + 32 * i + (lane & 31)];           // (|x|^2 - tau) / 2; +inf for rows past nq
-            const float big = fabsf(rq) * 0x1p-14f, margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
+            const int arow = wm + 32 * i + (lane & 31);
+            const float rq = stage[3 * TM + arow];                                // (|x|^2 - tau) / 2; +inf for rows past nq
+            const float big = fabsf(rq) * 0x1p-14f;
+            float margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
+            // inexact operands: |bf16(x).bf16(y) - x.y| <= (2^-7 + 2^-16) sum |x_i y_i| <= (2^-8 + 2^-17) (|x|^2 + |y|^2); the fp32
+            // chain that decides in the end, the accumulation inside the matrix pipe and the pieces of the thresholds add a few
+            // 2^-24 of the same sum: 1.02 x 2^-8 covers them.  |y|^2 <= bn_max for every column.
+            if (approx) margin += 1.02f * 0x1p-8f * (stage[2 * arow] + p.bn_max) + 0x1p-20f * fabsf(rq);
             uint32_t r[3];
             bf16_split3(fabsf(rq) == INFINITY ? rq : rq - margin, r);
             u32x4 w;
@@ -864,7 +912,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 uint32_t surv[MT][NJ];
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
-                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn);
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
@@ -1262,7 +1310,9 @@ struct pf_flat {
     size_t nb = 0;
     uint32_t d = 0;
     float *xb = nullptr, *bn = nullptr;
-    uint16_t *xb16 = nullptr;     // bf16 image of the base matrix: present only if EVERY value passed the on-device exactness check
+    uint16_t *xb16 = nullptr;     // bf16 image of the base matrix (d = 64 or 128): rows of d values + AUX16 threshold words, nearest-even
+    bool exact16 = false;         // EVERY value of the base passed the on-device exactness check: the image is the matrix itself
+    float bn_max = 0.f;           // largest row norm (the margin of the bf16 tiles as a filter over inexact operands)
     bool use16 = true;            // pf_flat_exact16: the caller may switch the 16-bit operand path off
     // workspace (grown outside graph capture)
     void *ws = nullptr;
@@ -1366,7 +1416,14 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             uint32_t inexact = 1;
             if (e == hipSuccess) e = hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost);
             (void)hipFree(flag);
-            if (inexact && f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }     // one inexact value: fp32 operands only
+            f->exact16 = f->xb16 && !inexact;       // inexact values: the image stays, as the operand of a conservative filter
+        }
+        if (e == hipSuccess && f->xb16) {            // largest row norm; a norm that is not finite rules the filter out
+            std::vector<float> norms(nb);
+            e = hipMemcpy(norms.data(), f->bn, nb * 4, hipMemcpyDeviceToHost);
+            bool finite = true;
+            for (float v : norms) { finite = finite && std::isfinite(v); if (v > f->bn_max) f->bn_max = v; }
+            if (!finite) { (void)hipFree(f->xb16); f->xb16 = nullptr; f->exact16 = false; }
         }
     }
     if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
@@ -1386,7 +1443,7 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
 pf_status pf_flat_exact16(pf_flat *f, int mode, int *active) {
     if (!f || mode < -1 || mode > 1) return fail(PF_ERR_INVALID_ARG, "pf_flat_exact16: index, and mode -1 (query), 0 (off) or 1 (on where exact)");
     if (mode >= 0) f->use16 = mode == 1;
-    if (active) *active = f->xb16 && f->use16 ? 1 : 0;
+    if (active) *active = f->xb16 && f->use16 ? (f->exact16 ? 2 : 1) : 0;
     return PF_OK;
 }
 
@@ -1435,7 +1492,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
                                                false, b16 ? qbad : nullptr, 128u);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
-    t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad;
+    t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = f->exact16 ? 1u : 0u; t.bn_max = f->bn_max;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};

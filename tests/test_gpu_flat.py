@@ -392,6 +392,37 @@ def test_exact16_dense_survivors_and_far_thresholds():
     assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("law", ["gaussian", "mixed_norms", "integers_with_one_fraction"])
+def test_bf16_filter_over_inexact_operands_is_bit_identical(law):
+    """operands that are NOT exactly representable: the bf16 tiles run as a conservative filter (thresholds lowered by the bound
+    on the operands' rounding) and every survivor is re-evaluated by the fp32 chain -- (D, I) must equal the fp32-operand
+    loop's bit for bit, whatever the norms look like"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(17)
+    nb, nq, k, d = 60000, 200, 100, 128
+    if law == "gaussian":
+        xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
+    elif law == "mixed_norms":                                       # rows of very different length: the margin is priced on the largest
+        xb = rng.standard_normal((nb, d)) * rng.choice([0.01, 1.0, 30.0], (nb, 1))
+        xq = rng.standard_normal((nq, d)) * rng.choice([0.1, 1.0, 10.0], (nq, 1))
+    else:
+        xb, xq = rng.integers(0, 256, (nb, d)).astype(np.float64), rng.integers(0, 256, (nq, d)).astype(np.float64)
+        xb[777, 5] = 0.5                                             # one inexact value: the whole base counts as inexact
+    xb, xq = xb.astype(np.float32), xq.astype(np.float32)
+    f = pf.FlatL2(xb, _dev())
+    assert f.operands16() == 1 and not f.exact16()
+    q = torch.from_numpy(xq).to(_dev())
+    D1, I1 = f.search(q, k)
+    assert f.operands16(0) == 0
+    D0, I0 = f.search(q, k)
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    Dr, Ir = oracle.flat_l2_search(xb, xq[:4], k)                     # double accumulation, rounded once
+    if law == "integers_with_one_fraction":                          # every distance is a multiple of 1/4 below 2^24: exact either way
+        assert (I1[:4].cpu().numpy() == Ir).all() and (D1[:4].cpu().numpy() == Dr).all()
+    else:
+        assert np.allclose(D1[:4].cpu().numpy(), Dr, rtol=RTOL, atol=0)
+
+
 def test_exact16_path_refuses_inexact_data():
     """one value outside the exactly-representable set switches the path off: a fraction, a large integer, a huge d"""
     import prefhetch_amd as pf
@@ -401,11 +432,12 @@ def test_exact16_path_refuses_inexact_data():
     for bad in (0.5, 257.0, -300.0, 1e6):
         xb = base.copy()
         xb[1234, 77] = bad
-        assert not pf.FlatL2(xb, dev).exact16()
+        f = pf.FlatL2(xb, dev)
+        assert not f.exact16() and f.operands16() == 1                                                 # the image stays, as a filter's operand
     assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
     for d in (100, 192, 256):                                                                          # row lengths the bf16 tiles are not built for
-        assert not pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).exact16()
-    assert pf.FlatL2(base, dev).exact16()
+        assert pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).operands16() == 0
+    assert pf.FlatL2(base, dev).operands16() == 2
 
 
 def test_exact16_query_tile_falls_back_per_tile():
