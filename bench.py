@@ -408,8 +408,15 @@ def main():
         gg = torch.Generator(device=dev).manual_seed(SEED)
         flat_g = pf.FlatL2(torch.randn((args.nb, DIM), generator=gg, device=dev), dev)
         xq_g = torch.randn((B, DIM), generator=gg, device=dev)
-        variants["gaussian_k200_ms"] = timed_search(flat_g, xq_g, TOPK)
+        variants["gaussian_k200_ms"] = timed_search(flat_g, xq_g, TOPK)          # bf16 tiles as a conservative filter + fp32 chain on the survivors
         variants["gaussian_k100_ms"] = timed_search(flat_g, xq_g, 100)
+        if flat_g.operands16() == 1:
+            Dg, Ig = flat_g.search(xq_g, TOPK)
+            flat_g.operands16(0)
+            variants["gaussian_k200_fp32_operands_ms"] = timed_search(flat_g, xq_g, TOPK)
+            Df, If = flat_g.search(xq_g, TOPK)
+            variants["gaussian_fp32_operands_bit_identical"] = bool(torch.equal(If, Ig) and torch.equal(Df.view(torch.int32), Dg.view(torch.int32)))
+            del Dg, Ig, Df, If
         del flat_g, xq_g
 
     # The encrypted precise search at batch size (SURVEY.md 8(d)'s protocol-level figure, measured rather
@@ -489,7 +496,8 @@ def main():
                  "unit": "TFLOP/s", "frac": tf / BF16_MATRIX_PEAK_TF, "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b,
                  "operands": "bf16 with fp32 accumulation: every value of base and queries is an integer of magnitude <= 256 (checked on the device, "
                              "value by value), so every product and partial sum is exact and (D, I) equal the fp32-operand path's bit for bit "
-                             "(prefilter_variants.fp32_operands_bit_identical_to_timed_path); other data runs fp32 operands automatically",
+                             "(prefilter_variants.fp32_operands_bit_identical_to_timed_path); inexact data runs the same tiles as a conservative filter and the fp32 chain "
+                             "on the survivors (prefilter_variants.gaussian_*)",
                  "frac_of_fp32_matrix_peak_for_reference": tf / F32_MATRIX_PEAK_TF}
                 if exact16_active else
                 {"kernel": "k_l2_tile (+ k_select), whole stage", "bound": "mfma", "achieved": tf, "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",

@@ -63,16 +63,17 @@ __global__ void __launch_bounds__(256) k_row_norms(const float *__restrict__ x, 
     out[i] = acc;
 }
 
-// ---- bf16 operands for exactly-representable data --------------------------------------------------------------
+// ---- bf16 operands --------------------------------------------------------------------------------------------
 // SIFT-like vectors (the reference's dataset: 8-bit values stored as fp32) are integers of magnitude <= 256: exact in
 // bf16 (8 significant bits), every product x*y is an integer of at most 2^16 and, with d <= 128, every partial sum of a dot
 // product is an integer of magnitude <= 2^23 -- exactly representable in fp32.  The bf16 matrix instruction
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulation) therefore returns the same accumulator, bit for bit, as the k-ordered
-// fp32 fmaf chain of the f32 instruction, whatever order it adds in, at 16 times the rate; norms and the final
-// fmaf(-2, acc, |x|^2 + |y|^2) are computed by the same code on both paths.  Eligibility is CHECKED ON THE DEVICE, value by
-// value (integer, |v| <= 256): the base when the index is created (the 16-bit image is dropped if a single value fails), the
-// queries at the start of every search (per 128-query tile; a tile with an inexact value runs the fp32 loop).  Nothing is
-// assumed about the data, and a search needs no host synchronisation to pick its path.
+// fp32 fmaf chain of the f32 instruction, whatever order it adds in, at 16 times the rate.  Eligibility is CHECKED ON THE
+// DEVICE, value by value (integer, |v| <= 256): the base when the index is created, the queries at the start of every
+// search (per 128-query tile).  Nothing is assumed about the data, and a search needs no host synchronisation to pick its
+// path.  Operands that fail the check keep the bf16 tiles as a CONSERVATIVE FILTER (k_l2_tile16): the image is the nearest
+// bf16 of every value, the thresholds are lowered by the bound on that rounding, and the distance of every survivor is the
+// fp32 chain over the fp32 rows -- (D, I) are the fp32-operand loop's either way.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;      // 16 bytes in registers (HIP's uint4 struct in an array stays in scratch)
 constexpr float BF16_EXACT_MAX = 256.f;
 __device__ __forceinline__ bool bf16_exact(float v) { return v == rintf(v) && fabsf(v) <= BF16_EXACT_MAX; }
@@ -814,8 +815,8 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             float margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
             // inexact operands: |bf16(x).bf16(y) - x.y| <= (2^-7 + 2^-16) sum |x_i y_i| <= (2^-8 + 2^-17) (|x|^2 + |y|^2); the fp32
             // chain that decides in the end, the accumulation inside the matrix pipe and the pieces of the thresholds add a few
-            // 2^-24 of the same sum: 1.02 x 2^-8 covers them.  |y|^2 <= bn_max for every column.
-            if (approx) margin += 1.02f * 0x1p-8f * (stage[2 * arow] + p.bn_max) + 0x1p-20f * fabsf(rq);
+            // 2^-24 of the same sum (about 4e-5 (|x|^2 + |y|^2) in all): 1.05 x 2^-8 covers them.  |y|^2 <= bn_max for every column.
+            if (approx) margin += 1.05f * 0x1p-8f * (stage[2 * arow] + p.bn_max) + 0x1p-20f * fabsf(rq);
             uint32_t r[3];
             bf16_split3(fabsf(rq) == INFINITY ? rq : rq - margin, r);
             u32x4 w;
