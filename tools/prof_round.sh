@@ -13,6 +13,9 @@ for pass in "a:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
             "c:GRBM_GUI_ACTIVE" "f:FETCH_SIZE" "w:WRITE_SIZE"; do
   bash tools/pmc_pass.sh ${tag}_ctpt_${pass%%:*} "${pass#*:}" ctpt 30 1024 > $O/${tag}_pmc_ctpt_${pass%%:*}.txt 2>&1
 done
+bash tools/pmc_flat.sh ${tag}_flat 3 1024 > $O/${tag}_pmc_flat_tiles.txt 2>&1
+[ -f exp_libs/libpf_fs.so ] && PREFHETCH_HIP_LIB=$R/exp_libs/libpf_fs.so python3 tools/flat_stamps.py > $O/${tag}_flat_stamps.txt 2>&1
+python3 tools/time_flat_gauss.py > $O/${tag}_flat_gaussian.txt 2>&1
 python3 tools/sweep_shapes.py > $O/${tag}_shapes_sweep.json 2> $O/${tag}_shapes_sweep.err
 python3 tools/sweep_flat.py > $O/${tag}_flat_sweep.json 2> $O/${tag}_flat_sweep.err
 python3 tools/time_ivfpq.py > $O/${tag}_ivfpq.json 2> $O/${tag}_ivfpq.err
