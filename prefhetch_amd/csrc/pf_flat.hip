@@ -1151,13 +1151,12 @@ __device__ __forceinline__ void radix_cut(uint64_t *keys, uint32_t &cnt, uint32_
 // One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
 // running top-k, or -- if the candidate list overflowed -- rescan the chunk exactly.
 template <uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
+__device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
     constexpr int SEL_COLS = SEL_ROUND / THREADS;
     __shared__ __align__(16) uint64_t keys[SEL_CAP];
     __shared__ uint32_t cnt;
     __shared__ uint64_t tau;
     const int tid = threadIdx.x;
-    const size_t q = blockIdx.x;
     const uint32_t k = p.k;
     const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
     const uint32_t nc = p.mode == 1 ? p.cand_cnt[q] : 0u;
@@ -1168,7 +1167,8 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
         else if (merge && i - c0 < nc) v = p.cand[q * p.cap + (i - c0)];     // c0 + nc <= k + cap <= SEL_CAP
         keys[i] = v;
     }
-    if (tid == 0) { cnt = merge ? c0 + nc : c0; tau = c0 == k ? p.state[q * k + k - 1] : KEY_INF; }
+    // (the state of a batch search is unordered between chunks -- merge_wave -- so the running threshold comes from p.tau)
+    if (tid == 0) { cnt = merge ? c0 + nc : c0; tau = c0 == k ? make_key(p.tau[q], 0xFFFFFFFFu) : KEY_INF; }
     __syncthreads();
     __shared__ uint32_t hist[256], ctl[20];
     bool done = false;
@@ -1259,6 +1259,131 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) {
             p.tau[q] = total == k ? __uint_as_float((uint32_t)(keys[k - 1] >> 32)) : INFINITY;
             p.cand_cnt[q] = 0;
         }
+    }
+}
+
+template <uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS) k_select(SelArgs p) { select_one<THREADS>(p, blockIdx.x); }
+
+// ---- merge by one WAVE per query (batches) -------------------------------------------------------------------------
+// The merge of a chunk's candidates into the running top-k is the step between two tile launches: with a 256-thread
+// workgroup per query its ~40 barrier-separated phases (histogram passes, sort steps) cost 19 us per call although the
+// work is a few hundred keys -- waves spent 58 % of their cycles parked (PMC).  Here a wave owns a query: the keys sit in
+// registers, the k-th smallest KEY (distance, then id: keys are unique, so exactly k survive and no plateau of ties needs a
+// special case) is found by radix selection over the bytes that actually differ (wave min / max first), and the survivors
+// go back to the state by ballot -- unsorted, no workgroup barrier anywhere.  (A first version also sorted them, in LDS:
+// one wave cannot hide the LDS round trip of 36 dependent sort stages and the kernel took 27 us.  Nothing needs the order
+// before the last chunk, whose merge sorts in select_one.)
+// A workgroup takes four queries; if any of them cannot go this way (candidate list overflowed -> exact rescan, first or
+// last chunk) the whole workgroup runs select_one() on its four queries in turn.
+constexpr uint32_t MW_VPT = SEL_CAP / 64;
+__device__ __forceinline__ void wave_sync() {                      // orders this wave's LDS traffic for the compiler; the hardware keeps it in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// inclusive prefix sum over the 64 lanes by DPP (no LDS round trips: a scan by __shfl_up is six dependent ds_bpermute)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);       // row_shr:8: every row of 16 holds its own scan
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);       // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);       // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uint32_t *hist, int lane) {
+    const uint32_t k = p.k, c0 = p.state_cnt[q], nc = p.cand_cnt[q], n = c0 + nc;
+    uint64_t v[MW_VPT];
+#pragma unroll
+    for (uint32_t e = 0; e < MW_VPT; ++e) {
+        v[e] = KEY_INF;
+        if (e * 64 < n) {                                          // wave-uniform
+            const uint32_t i = e * 64 + lane;
+            if (i < c0) v[e] = p.state[q * k + i];
+            else if (i < n) v[e] = p.cand[q * p.cap + (i - c0)];
+        }
+    }
+    uint64_t T = KEY_INF - 1;                                      // keep every real key when there are no more than k
+    if (n > k) {
+        // bits in which the keys differ at all: OR over (key ^ one of the keys); the bytes above the first of them are common
+        const uint64_t key0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v[0] >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v[0]);      // lane 0 holds a real key (n > k >= 1)
+        uint32_t dl = 0, dh = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < MW_VPT; ++e)
+            if (e * 64 < n && e * 64 + lane < n) { dl |= (uint32_t)(v[e] ^ key0); dh |= (uint32_t)((v[e] ^ key0) >> 32); }
+        const uint64_t x = ((uint64_t)__reduce_or_sync(~0ull, dh) << 32) | __reduce_or_sync(~0ull, dl);    // != 0: keys are unique
+        int shift = ((63 - __builtin_clzll(x | 1ull)) / 8) * 8;
+        uint64_t prefix = shift >= 56 ? 0 : (key0 >> (shift + 8)) << (shift + 8), mask = shift >= 56 ? 0 : ~0ull << (shift + 8);
+        uint32_t need = k;
+        for (;; shift -= 8) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
+            wave_sync();
+#pragma unroll
+            for (uint32_t e = 0; e < MW_VPT; ++e)
+                if (e * 64 < n && e * 64 + lane < n && (v[e] & mask) == prefix) atomicAdd(&hist[(uint32_t)(v[e] >> shift) & 255u], 1u);
+            wave_sync();
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t incl = wave_incl_scan(h0 + h1 + h2 + h3);
+            const int L = __builtin_ctzll(__ballot(incl >= need));          // the lane whose four bins hold the need-th key (wave-uniform)
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, L), b1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, L),
+                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)h2, L), b3 = (uint32_t)__builtin_amdgcn_readlane((int)h3, L);
+            uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (b0 + b1 + b2 + b3);
+            uint32_t bin = 4 * L, cnt_bin = b0;
+            if (cum + b0 < need) { cum += b0; ++bin; cnt_bin = b1;
+                if (cum + b1 < need) { cum += b1; ++bin; cnt_bin = b2;
+                    if (cum + b2 < need) { cum += b2; ++bin; cnt_bin = b3; } } }
+            need -= cum;
+            prefix |= (uint64_t)bin << shift;
+            mask |= 0xFFull << shift;
+            if (cnt_bin == need || shift == 0) {                   // the whole bin is wanted (always so at the last byte: keys are unique)
+                T = prefix | ~mask;
+                break;
+            }
+        }
+    }
+    // compaction: keys <= T go back to the state, by ballot -- UNSORTED (nothing between two chunks needs the order: the next
+    // merge selects again, the tile kernel only wants the k-th distance; the last chunk's merge sorts, in select_one)
+    uint32_t total = 0, dmax = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < MW_VPT; ++e) {
+        if (e * 64 < n) {
+            const bool keep = v[e] <= T;
+            const uint64_t m = __ballot(keep);
+            const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (keep && pos < k) {
+                p.state[q * k + pos] = v[e];
+                const uint32_t db = (uint32_t)(v[e] >> 32);
+                dmax = db > dmax ? db : dmax;
+            }
+            total += (uint32_t)__popcll(m);
+        }
+    }
+    total = total < k ? total : k;                                  // (unique keys: exactly min(n, k))
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(dmax, d); dmax = o > dmax ? o : dmax; }
+    if (lane == 0) {
+        p.state_cnt[q] = total;
+        p.tau[q] = total == k ? __uint_as_float(dmax) : INFINITY;   // distances are >= 0: their bit patterns order like the values
+        p.cand_cnt[q] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_merge4(SelArgs p, uint32_t nq) {
+    __shared__ uint32_t hist[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t q0 = (size_t)blockIdx.x * 4;
+    bool fast = p.mode == 1 && !p.first && !p.last;
+    for (uint32_t j = 0; j < 4 && fast; ++j)
+        if (q0 + j < nq) fast = p.cand_cnt[q0 + j] <= p.cap && p.state_cnt[q0 + j] + p.cand_cnt[q0 + j] <= SEL_CAP;      // workgroup-uniform
+    if (fast) {
+        if (q0 + wave < nq) merge_wave(p, q0 + wave, hist[wave], lane);
+        return;
+    }
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (q0 + j < nq) select_one<256>(p, q0 + j);               // workgroup-uniform
+        __syncthreads();
     }
 }
 
@@ -1542,6 +1667,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     };
     auto launch_select = [&]() {
         if (nq <= 256) hipLaunchKernelGGL(k_select<1024>, dim3((unsigned)nq), dim3(1024), 0, s, a);
+        else if (a.mode == 1 && !a.first && !a.last) hipLaunchKernelGGL(k_merge4, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a, (uint32_t)nq);   // a wave per query
         else hipLaunchKernelGGL(k_select<256>, dim3((unsigned)nq), dim3(256), 0, s, a);
     };
     // bootstrap chunk through the slab
