@@ -1291,38 +1291,46 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);       // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uint32_t *hist, int lane) {
-    const uint32_t k = p.k, c0 = p.state_cnt[q], nc = p.cand_cnt[q], n = c0 + nc;
-    uint64_t v[MW_VPT];
-#pragma unroll
-    for (uint32_t e = 0; e < MW_VPT; ++e) {
-        v[e] = KEY_INF;
-        if (e * 64 < n) {                                          // wave-uniform
-            const uint32_t i = e * 64 + lane;
-            if (i < c0) v[e] = p.state[q * k + i];
-            else if (i < n) v[e] = p.cand[q * p.cap + (i - c0)];
-        }
-    }
-    uint64_t T = KEY_INF - 1;                                      // keep every real key when there are no more than k
+// The k smallest of n unique 64-bit keys held by one wave (slot e of lane l is element e * 64 + l < n; hi_at(e) / lo_at(e) yield
+// the distance word and the id word of its key) go to the state of query q, unordered; the k-th distance becomes the query's
+// threshold.  All tests run on the 32-bit halves (a pass over distance bytes never touches the ids).
+// `opaque`: a register lo_at() may depend on, made opaque once per pass (ids computed from the slot number would otherwise all be
+// formed ahead of the pass loop and kept).  (Tried for the 8192-row bootstrap as well, 128 computed keys per lane: 40 us against
+// the workgroup version's 32 -- one wave serialises on the few histogram bins the leading bytes fall into.)
+template <uint32_t VPT, class HiAt, class LoAt>
+__device__ __forceinline__ void wave_keep_k_smallest(const SelArgs &p, const size_t q, uint32_t n, uint32_t *hist, int lane, uint32_t &opaque,
+                                                     HiAt &&hi_at, LoAt &&lo_at) {
+    const uint32_t k = p.k;
+    uint32_t Thi = (uint32_t)((KEY_INF - 1) >> 32), Tlo = (uint32_t)(KEY_INF - 1);     // keep every real key when there are no more than k
     if (n > k) {
         // bits in which the keys differ at all: OR over (key ^ one of the keys); the bytes above the first of them are common
-        const uint64_t key0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v[0] >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v[0]);      // lane 0 holds a real key (n > k >= 1)
-        uint32_t dl = 0, dh = 0;
+        const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi_at(0)), l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo_at(0));
+        uint32_t dl = 0, dh = 0;                                    // (lane 0 holds a real key: n > k >= 1)
 #pragma unroll
-        for (uint32_t e = 0; e < MW_VPT; ++e)
-            if (e * 64 < n && e * 64 + lane < n) { dl |= (uint32_t)(v[e] ^ key0); dh |= (uint32_t)((v[e] ^ key0) >> 32); }
-        const uint64_t x = ((uint64_t)__reduce_or_sync(~0ull, dh) << 32) | __reduce_or_sync(~0ull, dl);    // != 0: keys are unique
-        int shift = ((63 - __builtin_clzll(x | 1ull)) / 8) * 8;
-        uint64_t prefix = shift >= 56 ? 0 : (key0 >> (shift + 8)) << (shift + 8), mask = shift >= 56 ? 0 : ~0ull << (shift + 8);
+        for (uint32_t e = 0; e < VPT; ++e)
+            if (e * 64 < n && e * 64 + lane < n) { dh |= hi_at(e) ^ h_first; dl |= lo_at(e) ^ l_first; }
+        dh = __reduce_or_sync(~0ull, dh); dl = __reduce_or_sync(~0ull, dl);            // not both zero: keys are unique
+        int shift = dh ? 32 + ((31 - __builtin_clz(dh)) / 8) * 8 : ((31 - __builtin_clz(dl | 1u)) / 8) * 8;
+        // prefix / mask of the bytes already fixed, as (distance word, id word)
+        uint32_t p_hi, m_hi, p_lo = 0, m_lo = 0;
+        if (shift >= 32) { const int s2 = shift - 32; m_hi = s2 >= 24 ? 0u : ~0u << (s2 + 8); p_hi = h_first & m_hi; }
+        else { m_hi = ~0u; p_hi = h_first; m_lo = shift >= 24 ? 0u : ~0u << (shift + 8); p_lo = l_first & m_lo; }
         uint32_t need = k;
         for (;; shift -= 8) {
+            asm volatile("" : "+v"(opaque));
 #pragma unroll
             for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
             wave_sync();
+            if (shift >= 32) {                                      // wave-uniform: a byte of the distance
+                const int s2 = shift - 32;
 #pragma unroll
-            for (uint32_t e = 0; e < MW_VPT; ++e)
-                if (e * 64 < n && e * 64 + lane < n && (v[e] & mask) == prefix) atomicAdd(&hist[(uint32_t)(v[e] >> shift) & 255u], 1u);
+                for (uint32_t e = 0; e < VPT; ++e)
+                    if (e * 64 < n && e * 64 + lane < n) { const uint32_t h = hi_at(e); if ((h & m_hi) == p_hi) atomicAdd(&hist[(h >> s2) & 255u], 1u); }
+            } else {                                                // a byte of the id: only among keys of the k-th distance
+#pragma unroll
+                for (uint32_t e = 0; e < VPT; ++e)
+                    if (e * 64 < n && e * 64 + lane < n && hi_at(e) == p_hi) { const uint32_t l = lo_at(e); if ((l & m_lo) == p_lo) atomicAdd(&hist[(l >> shift) & 255u], 1u); }
+            }
             wave_sync();
             const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
             const uint32_t incl = wave_incl_scan(h0 + h1 + h2 + h3);
@@ -1335,32 +1343,34 @@ __device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uin
                 if (cum + b1 < need) { cum += b1; ++bin; cnt_bin = b2;
                     if (cum + b2 < need) { cum += b2; ++bin; cnt_bin = b3; } } }
             need -= cum;
-            prefix |= (uint64_t)bin << shift;
-            mask |= 0xFFull << shift;
+            if (shift >= 32) { p_hi |= bin << (shift - 32); m_hi |= 0xFFu << (shift - 32); }
+            else { p_lo |= bin << shift; m_lo |= 0xFFu << shift; }
             if (cnt_bin == need || shift == 0) {                   // the whole bin is wanted (always so at the last byte: keys are unique)
-                T = prefix | ~mask;
+                Thi = p_hi | ~m_hi; Tlo = p_lo | ~m_lo;
                 break;
             }
         }
     }
-    // compaction: keys <= T go back to the state, by ballot -- UNSORTED (nothing between two chunks needs the order: the next
+    asm volatile("" : "+v"(opaque));
+    // compaction: keys <= T go to the state, by ballot -- UNSORTED (nothing between two chunks needs the order: the next
     // merge selects again, the tile kernel only wants the k-th distance; the last chunk's merge sorts, in select_one)
     uint32_t total = 0, dmax = 0;
 #pragma unroll
-    for (uint32_t e = 0; e < MW_VPT; ++e) {
+    for (uint32_t e = 0; e < VPT; ++e) {
         if (e * 64 < n) {
-            const bool keep = v[e] <= T;
+            const uint32_t h = hi_at(e), l = lo_at(e);
+            const bool keep = e * 64 + lane < n && (h < Thi || (h == Thi && l <= Tlo));
             const uint64_t m = __ballot(keep);
             const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1));
             if (keep && pos < k) {
-                p.state[q * k + pos] = v[e];
-                const uint32_t db = (uint32_t)(v[e] >> 32);
-                dmax = db > dmax ? db : dmax;
+                p.state[q * k + pos] = ((uint64_t)h << 32) | l;
+                dmax = h > dmax ? h : dmax;
             }
             total += (uint32_t)__popcll(m);
         }
     }
     total = total < k ? total : k;                                  // (unique keys: exactly min(n, k))
+    // the k-th distance: largest kept one (six ds_bpermute steps on one word, once)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(dmax, d); dmax = o > dmax ? o : dmax; }
     if (lane == 0) {
@@ -1368,6 +1378,23 @@ __device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uin
         p.tau[q] = total == k ? __uint_as_float(dmax) : INFINITY;   // distances are >= 0: their bit patterns order like the values
         p.cand_cnt[q] = 0;
     }
+}
+
+// merge of a chunk's candidates into the running state
+__device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uint32_t *hist, int lane) {
+    const uint32_t k = p.k, c0 = p.state_cnt[q], nc = p.cand_cnt[q], n = c0 + nc;
+    uint64_t v[MW_VPT];
+#pragma unroll
+    for (uint32_t e = 0; e < MW_VPT; ++e) {
+        v[e] = KEY_INF;
+        if (e * 64 < n) {                                          // wave-uniform
+            const uint32_t i = e * 64 + lane;
+            if (i < c0) v[e] = p.state[q * k + i];
+            else if (i < n) v[e] = p.cand[q * p.cap + (i - c0)];
+        }
+    }
+    uint32_t unused = 0;
+    wave_keep_k_smallest<MW_VPT>(p, q, n, hist, lane, unused, [&](uint32_t e) { return (uint32_t)(v[e] >> 32); }, [&](uint32_t e) { return (uint32_t)v[e]; });
 }
 
 __global__ void __launch_bounds__(256) k_merge4(SelArgs p, uint32_t nq) {
