@@ -178,7 +178,8 @@ pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_h
  * src/client/client_lib.cpp:122-156): for query q and each of its nprobe GIVEN lists, in the given order, the asymmetric
  * PQ distance and label of EVERY stored vector, unsorted; a query's results are contiguous, queries back to back;
  * list_sizes_host[q] = number of results of query q.  xq [nq][d] device, probe_host [nq][nprobe] host (-1 = skip),
- * D / I device buffers of `capacity` entries.  Synchronises `stream` once (staging of the probe ids). */
+ * D / I device buffers of `capacity` entries.  The probe ids and output offsets travel through pinned staging buffers owned by
+ * the index (an event, not a stream synchronisation, guards their reuse by the next call); probe_host may be reused on return. */
 pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 

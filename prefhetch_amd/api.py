@@ -398,8 +398,9 @@ class IvfPq:
         pq = _req(xq, torch.float32, self.device_index, "xq")
         probe = np.ascontiguousarray(probe, np.int64)
         nq, nprobe = probe.shape
-        sizes = self.list_sizes()
-        cap = int(sum(int(sizes[l]) for l in probe.ravel() if 0 <= l < self.nlist))
+        sizes = np.asarray(self.list_sizes(), dtype=np.uint64)
+        flat = probe.ravel()
+        cap = int(sizes[flat[(flat >= 0) & (flat < self.nlist)]].sum())
         D = torch.empty(max(cap, 1), dtype=torch.float32, device=self.device)
         I = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
         per_q = np.zeros(nq, np.uint64)

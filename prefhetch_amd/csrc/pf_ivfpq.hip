@@ -93,9 +93,14 @@ struct pf_ivfpq {
     uint64_t *d_off = nullptr;
     bool dirty = true;
     size_t ntotal = 0;
-    // per-call staging (probe ids, output offsets), grown on demand
+    // per-call staging (probe ids, output offsets), grown on demand: device copies and the pinned host buffers they are
+    // filled from; `staged` marks the end of the last call's copies (the next call waits for it before it refills the
+    // buffers -- in practice it has long passed: no stream synchronisation per call)
     int64_t *d_probe = nullptr;
     uint64_t *d_outoff = nullptr;
+    int64_t *pin_probe = nullptr;
+    uint64_t *pin_outoff = nullptr;
+    hipEvent_t staged = nullptr;
     size_t stage_cap = 0;
 };
 
@@ -137,6 +142,9 @@ pf_status pf_ivfpq_destroy(pf_ivfpq *h) {
         for (void *p : {(void *)h->centroids, (void *)h->codebooks, (void *)h->d_codes, (void *)h->d_ids, (void *)h->d_off,
                         (void *)h->d_probe, (void *)h->d_outoff})
             if (p) (void)hipFree(p);
+        if (h->pin_probe) (void)hipHostFree(h->pin_probe);
+        if (h->pin_outoff) (void)hipHostFree(h->pin_outoff);
+        if (h->staged) (void)hipEventDestroy(h->staged);
     }
     delete h;
     return PF_OK;
@@ -209,33 +217,39 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *h, const float *xq, const int64_t *pro
     PF_GUARD(h->device);
     pf_status st = flush_lists(h);
     if (st != PF_OK) return st;
-    std::vector<uint64_t> out_off(nq * nprobe);
+    const size_t need = nq * nprobe;
+    if (need > h->stage_cap) {
+        if (h->staged) PF_HIP(hipEventSynchronize(h->staged));
+        if (h->d_probe) PF_HIP(hipFree(h->d_probe));
+        if (h->d_outoff) PF_HIP(hipFree(h->d_outoff));
+        if (h->pin_probe) PF_HIP(hipHostFree(h->pin_probe));
+        if (h->pin_outoff) PF_HIP(hipHostFree(h->pin_outoff));
+        h->d_probe = nullptr; h->d_outoff = nullptr; h->pin_probe = nullptr; h->pin_outoff = nullptr; h->stage_cap = 0;
+        PF_HIP(hipMalloc((void **)&h->d_probe, need * 8));
+        PF_HIP(hipMalloc((void **)&h->d_outoff, need * 8));
+        PF_HIP(hipHostMalloc((void **)&h->pin_probe, need * 8, hipHostMallocDefault));
+        PF_HIP(hipHostMalloc((void **)&h->pin_outoff, need * 8, hipHostMallocDefault));
+        h->stage_cap = need;
+    }
+    if (!h->staged) PF_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
+    else PF_HIP(hipEventSynchronize(h->staged));                   // the previous call's copies out of the pinned buffers are done
     uint64_t total = 0;
     for (size_t q = 0; q < nq; ++q) {
         uint64_t per_q = 0;
         for (uint32_t j = 0; j < nprobe; ++j) {
             const int64_t l = probe_host[q * nprobe + j];
-            out_off[q * nprobe + j] = total + per_q;
+            h->pin_probe[q * nprobe + j] = l;
+            h->pin_outoff[q * nprobe + j] = total + per_q;
             if (l >= 0 && (uint64_t)l < h->nlist) per_q += h->h_ids[l].size();
         }
         list_sizes_host[q] = per_q;
         total += per_q;
     }
     if (total > capacity) return fail(PF_ERR_INVALID_ARG, "output capacity too small for the probed lists");
-    const size_t need = nq * nprobe;
-    if (need > h->stage_cap) {
-        if (h->d_probe) PF_HIP(hipFree(h->d_probe));
-        if (h->d_outoff) PF_HIP(hipFree(h->d_outoff));
-        h->d_probe = nullptr; h->d_outoff = nullptr; h->stage_cap = 0;
-        PF_HIP(hipMalloc((void **)&h->d_probe, need * 8));
-        PF_HIP(hipMalloc((void **)&h->d_outoff, need * 8));
-        h->stage_cap = need;
-    }
     hipStream_t s = as_stream(stream);
-    // pageable-host copies: hipMemcpyAsync from pageable memory returns after staging, so the vectors may go out of scope
-    PF_HIP(hipMemcpyAsync(h->d_probe, probe_host, need * 8, hipMemcpyHostToDevice, s));
-    PF_HIP(hipMemcpyAsync(h->d_outoff, out_off.data(), need * 8, hipMemcpyHostToDevice, s));
-    PF_HIP(hipStreamSynchronize(s));
+    PF_HIP(hipMemcpyAsync(h->d_probe, h->pin_probe, need * 8, hipMemcpyHostToDevice, s));
+    PF_HIP(hipMemcpyAsync(h->d_outoff, h->pin_outoff, need * 8, hipMemcpyHostToDevice, s));
+    PF_HIP(hipEventRecord(h->staged, s));
     ScanArgs a{xq, h->centroids, h->codebooks, h->d_codes, h->d_ids, h->d_off, h->d_probe, h->d_outoff, D, I, h->d, h->M, h->dsub, nprobe, h->nlist};
     hipLaunchKernelGGL(k_ivfpq_scan, dim3((unsigned)need), dim3(256), h->M * KSUB * 4, s, a);
     PF_HIP(hipGetLastError());
