@@ -423,6 +423,33 @@ def test_bf16_filter_over_inexact_operands_is_bit_identical(law):
         assert np.allclose(D1[:4].cpu().numpy(), Dr, rtol=RTOL, atol=0)
 
 
+@pytest.mark.parametrize("nb,nq,k,d,law", [(100, 200, 50, 128, "int"), (8192, 130, 20, 128, "int"), (8193, 130, 20, 128, "int"), (20000, 65, 1024, 128, "int"),
+                                            (50000, 300, 1024, 64, "int"), (30000, 129, 7, 64, "gauss"), (9000, 70, 200, 128, "gauss"),
+                                            (70000, 257, 300, 128, "mixed")])
+def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
+    """shapes around the seams of the batch path: a base smaller than one tile, exactly / one past the bootstrap chunk, the smallest
+    batch, k = 1024 (merges of 2048 keys by one wave), d = 64, a single filtered tile -- bf16 tiles vs fp32 operands, bit for bit"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(nb + nq)
+    if law == "int":
+        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+    elif law == "gauss":
+        xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
+    else:
+        xb, xq = rng.standard_normal((nb, d)) * rng.choice([0.01, 1, 50], (nb, 1)), rng.standard_normal((nq, d))
+    xb, xq = xb.astype(np.float32), xq.astype(np.float32)
+    f = pf.FlatL2(xb, _dev())
+    q = torch.from_numpy(xq).to(_dev())
+    assert f.operands16() == (2 if law == "int" else 1)
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    if law == "int":
+        Dr, Ir = oracle.flat_l2_search(xb, xq[:3], k)
+        assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
+
+
 def test_exact16_path_refuses_inexact_data():
     """one value outside the exactly-representable set switches the path off: a fraction, a large integer, a huge d"""
     import prefhetch_amd as pf
