@@ -450,6 +450,31 @@ def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
         assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
 
 
+def test_bf16_filter_worst_case_rounding():
+    """the bound the filter margin is priced on, met with equality: every coordinate is +-(1 + 2^-8) c -- exactly halfway between two
+    bf16 values, rounded DOWN by ties-to-even, so every product loses the full 2^-7 -- and queries are copies of base rows (x parallel
+    to y, Cauchy-Schwarz tight, all rows of one norm): the true neighbours are where the bf16 dot product is furthest from the fp32 one"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(23)
+    nb, nq, k, d = 30000, 160, 10, 128
+    mag = np.float32(3.0) * np.float32(1.0 + 2.0 ** -8)
+    xb = (rng.integers(0, 2, (nb, d)) * 2 - 1).astype(np.float32) * mag
+    xq = (rng.integers(0, 2, (nq, d)) * 2 - 1).astype(np.float32) * mag
+    picks = rng.integers(8192, nb, 100)                                # rows behind the bootstrap chunk: only the filter can find them
+    xq[:100] = xb[picks]
+    xq[50:100, :3] *= -1                                              # near-duplicates: three coordinates flipped
+    f = pf.FlatL2(xb, _dev())
+    assert f.operands16() == 1
+    q = torch.from_numpy(xq).to(_dev())
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    got = I1.cpu().numpy()
+    assert all(picks[i] in got[i] for i in range(100))               # each planted row is among its query's results
+    assert (D1[:50, 0].cpu().numpy() == 0).all()
+
+
 def test_exact16_path_refuses_inexact_data():
     """one value outside the exactly-representable set switches the path off: a fraction, a large integer, a huge d"""
     import prefhetch_amd as pf
