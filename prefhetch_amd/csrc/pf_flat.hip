@@ -143,6 +143,23 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
     }
 }
 
+// Inexact base: the column's share of the filter margin goes into its threshold words, b0 + b1 + b2 = |y|^2 (1/2 - 1.05 x 2^-8)
+// (k_l2_tile16: the bound on the operands' rounding is (2^-8 + 2^-17)(|x|^2 + |y|^2), priced per column -- a base whose rows
+// differ widely in length would otherwise pay the longest row's margin in every column).
+constexpr float BF16_MARGIN = 1.05f * 0x1p-8f;
+__global__ void __launch_bounds__(256) k_aux_margin(uint16_t *__restrict__ x16, const float *__restrict__ norms, size_t n, uint32_t d, uint32_t pitch16) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    uint32_t b[3];
+    bf16_split3(norms[r] * (0.5f - BF16_MARGIN), b);
+    u32x4 w;
+    w[0] = (b[0] ^ BF16_SIGN) | ((b[1] ^ BF16_SIGN) << 16);
+    w[1] = (b[2] ^ BF16_SIGN) | (BF16_ONE << 16);
+    w[2] = BF16_ONE | (BF16_ONE << 16);
+    w[3] = 0;
+    *reinterpret_cast<u32x4 *>(x16 + r * pitch16 + d) = w;
+}
+
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 // One 128x128 tile of distances per workgroup (256 threads = 4 waves, each wave a 64x64 quadrant as
@@ -721,7 +738,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     using GEO = GeoBatch;
     constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
-    constexpr size_t SMEM = FILTER || 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback (unfiltered launch) borrows this LDS
+    constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
     static_assert(PITCH % 32 == 16 && TN == 128 && TM == 128, "odd row pitch in 16-byte units; 128 x 128 tiles");
     __shared__ __align__(16) char smem[SMEM];
     __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
@@ -740,15 +757,17 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     // unfiltered bootstrap launch writes distances, so it runs the fp32 tile body; a filtered launch keeps the bf16 tiles as a
     // CONSERVATIVE FILTER (row thresholds lowered by the bound on the rounding of the operands, below) and flush() evaluates
     // the survivors with the fp32 chain.
-    const bool approx = !p.base_exact || p.q_inexact[qt];           // workgroup-uniform
-    if constexpr (!FILTER) {
-        if (approx) {
-            for (uint32_t ct = ct0; ct < ct1; ++ct) {
-                l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
-                __syncthreads();
-            }
-            return;
+    // A query tile whose candidate lists overflowed in an earlier chunk (bit 1, set by the selection kernel) is one the bf16
+    // tiles do not filter -- every distance within the rounding of the operands of the threshold: margin ~ 2^-8 (|x|^2 + |y|^2)
+    // against a spread of distances far below that -- and runs fp32 tiles from then on.
+    const uint32_t qflags = p.q_inexact[qt];                        // workgroup-uniform
+    const bool approx = !p.base_exact || (qflags & 1u);
+    if ((!FILTER && approx) || (FILTER && (qflags & 2u))) {
+        for (uint32_t ct = ct0; ct < ct1; ++ct) {
+            l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
+            __syncthreads();
         }
+        return;
     }
     const size_t q0 = (size_t)qt * TM;
     const uint32_t q_valid = (uint32_t)(p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM);
@@ -815,8 +834,10 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             float margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
             // inexact operands: |bf16(x).bf16(y) - x.y| <= (2^-7 + 2^-16) sum |x_i y_i| <= (2^-8 + 2^-17) (|x|^2 + |y|^2); the fp32
             // chain that decides in the end, the accumulation inside the matrix pipe and the pieces of the thresholds add a few
-            // 2^-24 of the same sum (about 4e-5 (|x|^2 + |y|^2) in all): 1.05 x 2^-8 covers them.  |y|^2 <= bn_max for every column.
-            if (approx) margin += 1.05f * 0x1p-8f * (stage[2 * arow] + p.bn_max) + 0x1p-20f * fabsf(rq);
+            // 2^-24 of the same sum (about 4e-5 (|x|^2 + |y|^2) in all): 1.05 x 2^-8 covers them.
+            // An inexact base carries its columns' share in their threshold words (k_aux_margin); an exact base facing an inexact query
+            // tile does not, and the row pays for the longest column.
+            if (approx) margin += BF16_MARGIN * (stage[2 * arow] + (p.base_exact ? p.bn_max : 0.f)) + 0x1p-20f * fabsf(rq);
             uint32_t r[3];
             bf16_split3(fabsf(rq) == INFINITY ? rq : rq - margin, r);
             u32x4 w;
@@ -934,6 +955,8 @@ struct SelArgs {
     int mode, first, last;
     float *D; int64_t *I;                    // written when last (either may be null)
     uint32_t *packed;                        // written when last, if not null: [nq][k]{id low word, id high word, distance bits}
+    uint32_t *q_flags;                       // bf16 tiles: per 128-query tile, bit 1 is set here when a candidate list of the tile overflowed
+    float bn_max; uint32_t base_exact;       // ... or when the bootstrap predicts that the tiles will not filter (select_one)
 };
 
 // final results of one query position: the caller's (D, I) and / or the 12-byte exchange record of the multi-GPU gather
@@ -1161,6 +1184,9 @@ __device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
     const uint32_t c0 = p.first ? 0u : p.state_cnt[q];
     const uint32_t nc = p.mode == 1 ? p.cand_cnt[q] : 0u;
     const bool merge = p.mode == 1 && nc <= p.cap;            // workgroup-uniform
+    // A list that overflowed: this chunk is rescanned exactly (below), and the bf16 tiles -- if they produced it -- are not
+    // filtering for this query tile (distances closer together than the operands' rounding resolves): its later chunks take fp32 tiles.
+    if (p.mode == 1 && !merge && p.q_flags && threadIdx.x == 0) atomicOr(&p.q_flags[q / 128], 2u);
     for (uint32_t i = tid; i < SEL_CAP; i += THREADS) {
         uint64_t v = KEY_INF;
         if (i < c0) v = p.state[q * k + i];
@@ -1258,6 +1284,17 @@ __device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
             p.state_cnt[q] = total;
             p.tau[q] = total == k ? __uint_as_float((uint32_t)(keys[k - 1] >> 32)) : INFINITY;
             p.cand_cnt[q] = 0;
+            // Bootstrap, inexact operands: will the bf16 tiles filter for this query?  Their threshold sits a margin m = 1.05 x 2^-8
+            // (|x|^2 + |y|^2) above the k-th distance (in inner-product units; 2 m in distance).  The sorted results give the
+            // density of base rows there -- k / 2 rows between the distances of rank k / 2 and k, per bootstrap chunk -- and with it
+            // the rows the margin lets through on top of the k a chunk is sized for.  More than 1.5 k of them (distances packed far
+            // closer than the operands' rounding resolves: e.g. every row at almost the same distance from the query) and the
+            // tile takes fp32 tiles from the first chunk on instead of finding out by overflowing a candidate list.
+            if (p.mode == 0 && p.first && p.q_flags && total == k && k >= 8 && (!p.base_exact || (p.q_flags[q / 128] & 1u))) {
+                const float dk = __uint_as_float((uint32_t)(keys[k - 1] >> 32)), dh = __uint_as_float((uint32_t)(keys[k / 2 - 1] >> 32));
+                const float window = 2.f * BF16_MARGIN * (p.qn[q] + p.bn_max);
+                if (window * (0.5f * (float)k) > 1.5f * (float)k * (dk - dh)) atomicOr(&p.q_flags[q / 128], 2u);
+            }
         }
     }
 }
@@ -1570,6 +1607,11 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             if (e == hipSuccess) e = hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost);
             (void)hipFree(flag);
             f->exact16 = f->xb16 && !inexact;       // inexact values: the image stays, as the operand of a conservative filter
+            if (e == hipSuccess && f->xb16 && !f->exact16) {
+                hipLaunchKernelGGL(k_aux_margin, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb16, f->bn, nb, d, d + AUX16);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
         }
         if (e == hipSuccess && f->xb16) {            // largest row norm; a norm that is not finite rules the filter out
             std::vector<float> norms(nb);
@@ -1653,7 +1695,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
-    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I; a.packed = packed;
+    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I; a.packed = packed; a.q_flags = b16 ? qbad : nullptr; a.bn_max = f->bn_max; a.base_exact = f->exact16 ? 1u : 0u;
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = b16 ? 2 : nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
