@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
     l2_tile_f32<FILTER, GEO, FAST, AGG>(p, smem, j % p.n_qtiles, (j / p.n_qtiles) * 8 + xcd);
 }
 
-// ---- bf16 tiles (exactly-representable data, d = 64 or 128) ---------------------------------------------------------
+// ---- bf16 tiles (d = 64 or 128) ---------------------------------------------------------------------------------------
 // What the matrix pipe computes here is the FILTER VALUE itself, not the dot product: a ninth k-step adds the threshold,
 //     acc = x.y - |y|^2/2 - R,         R = (|x|^2 - tau)/2 - margin,
 // the column's half coming with the base row (three bf16 pieces behind its d values, k_rows_prep), the row's half built once
@@ -570,10 +570,12 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 // instructions inside the tile loop.
 // One workgroup keeps the bf16 image of its 128-query tile in registers (whole k) and walks `group` consecutive 128-row
 // column tiles: a tile of the base image (rows of d values + 8 threshold words = PITCH bytes) is one contiguous block of
-// memory and is copied as such, 16 bytes per lane, into one of two LDS buffers (the odd row pitch in 16-byte units makes
-// ds_read_b128 of 32 consecutive rows conflict-free): while the matrix pipe and the epilogue work on tile t, the loads of
-// tile t+2 are in flight in registers and tile t+1 sits in the other buffer -- one barrier per tile.
-// A query tile with a value that is NOT exactly representable (q_inexact, set on the device) runs the fp32 tile body here.
+// memory and is copied as such by LDS-DMA into one of two LDS buffers (the odd row pitch in 16-byte units makes ds_read_b128
+// of 32 consecutive rows conflict-free): while the matrix pipe and the sign sweep work on tile t, tile t+1 is on its way
+// into the other buffer -- one barrier per tile.
+// Inexact operands (a base or a query tile with a value that is not exactly representable; flags set on the device): the
+// same tiles as a conservative filter -- margin 1.05 x 2^-8 (|x|^2 + |y|^2) on the thresholds, the survivors' distances by
+// the fp32 chain over the fp32 rows (flush) -- and fp32 tiles where that filter cannot help (k_l2_tile16, select_one).
 struct Pend16 {
     static constexpr uint32_t CAP = 1112;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
     uint32_t id[CAP];                  // base row
