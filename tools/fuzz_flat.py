@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Differential fuzz of FlatL2.search: bf16 tiles vs fp32 operands (bit for bit), and the oracle on integer-valued data.
+usage: tools/fuzz_flat.py [iterations] [seed]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import oracle  # noqa: E402
+import prefhetch_amd as pf  # noqa: E402
+
+dev = torch.device("cuda", 0)
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for it in range(iters):
+    d = int(rng.choice([64, 128]))
+    nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 60000)]))
+    nq = int(rng.choice([rng.integers(1, 70), rng.integers(70, 300), rng.integers(300, 700)]))
+    k = int(min(rng.choice([1, 7, 64, 200, 256, 257, 1024]), 1024))
+    law = str(rng.choice(["int", "ties", "gauss", "mixed", "dups", "neg"]))
+    if law == "int":
+        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+    elif law == "ties":
+        xb, xq = rng.integers(0, 3, (nb, d)), rng.integers(0, 3, (nq, d))
+    elif law == "neg":
+        xb, xq = rng.integers(-256, 257, (nb, d)), rng.integers(-256, 257, (nq, d))
+    elif law == "gauss":
+        xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
+    elif law == "mixed":
+        xb, xq = rng.standard_normal((nb, d)) * rng.choice([0.01, 1, 40], (nb, 1)), rng.standard_normal((nq, d)) * rng.choice([0.1, 1, 10], (nq, 1))
+    else:
+        xb = rng.integers(0, 256, (max(nb // 50, 1), d))[rng.integers(0, max(nb // 50, 1), nb)]      # every row ~50 times
+        xq = xb[rng.integers(0, nb, nq)]
+    xb, xq = np.ascontiguousarray(xb, np.float32), np.ascontiguousarray(xq, np.float32)
+    f = pf.FlatL2(xb, dev)
+    q = torch.from_numpy(xq).to(dev)
+    mode = f.operands16()
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)
+    ok = bool((I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all())
+    if ok and law in ("int", "ties", "neg", "dups"):
+        Dr, Ir = oracle.flat_l2_search(xb, xq[:2], k)
+        ok = bool((I1[:2].cpu().numpy() == Ir).all() and (D1[:2].cpu().numpy() == Dr).all())
+    print("%3d nb=%6d nq=%4d k=%4d d=%3d %-5s operands16=%d %s" % (it, nb, nq, k, d, law, mode, "ok" if ok else "MISMATCH"), flush=True)
+    bad += not ok
+    del f
+print("fuzz:", "all ok" if not bad else "%d MISMATCHES" % bad)
+sys.exit(1 if bad else 0)
