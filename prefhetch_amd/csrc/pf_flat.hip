@@ -595,7 +595,7 @@ struct Pend16 {
 #endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
-                                             uint32_t ct_base, int wm, int wn, bool approx) {
+                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid) {
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
     const int lane = tid & 63;
@@ -630,7 +630,18 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
         const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
         if (approx) {                                                 // workgroup-uniform
             // inexact operands: the distance of a survivor is the k-ordered fp32 chain over the fp32 rows -- what the fp32 tiles
-            // and the oracle evaluate -- one lane per survivor (the order of the additions is part of the result)
+            // and the oracle evaluate -- one lane per survivor (the order of the additions is part of the result).  A lane
+            // reading its own two rows 16 bytes at a time makes the texture path see 64 different cache lines per instruction; the
+            // query rows are only 128 different ones, so -- when the tile buffers are free: the walk's last flush -- they are
+            // copied into LDS once, coalesced (row pitch D * 4 + 16 bytes: conflict-free 16-byte reads by 64 different rows).
+            constexpr uint32_t XP = D * 4 + 16;
+            if (xstage) {
+                for (uint32_t i = tid; i < 128 * (D / 4); i += 256) {
+                    const uint32_t row = i / (D / 4), seg = i % (D / 4);
+                    *reinterpret_cast<float4 *>(xstage + row * XP + seg * 16) =
+                        reinterpret_cast<const float4 *>(p.xq + (q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)D)[seg];
+                }
+            }
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
@@ -640,12 +651,22 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             for (uint32_t e = tid; e < n; e += 256) {
                 const uint32_t loc = pd.loc[e], id = pd.id[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
                 if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
-                const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D), *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
+                const float4 *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
                 float acc = 0.f;
+                if (xstage) {
+                    const float4 *x = reinterpret_cast<const float4 *>(xstage + row * XP);
+#pragma unroll 8
+                    for (int t = 0; t < D / 4; ++t) {
+                        const float4 a = x[t], b = y[t];
+                        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                    }
+                } else {
+                    const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D);
 #pragma unroll 4
-                for (int t = 0; t < D / 4; ++t) {
-                    const float4 a = x[t], b = y[t];
-                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                    for (int t = 0; t < D / 4; ++t) {
+                        const float4 a = x[t], b = y[t];
+                        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                    }
                 }
                 const float dist = fmaf(-2.f, acc, sA[2 * row] + p.bn[id]);
                 p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
@@ -936,7 +957,8 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 uint32_t surv[MT][NJ];
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
-                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx);
+                // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
