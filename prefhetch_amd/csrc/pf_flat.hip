@@ -1090,6 +1090,20 @@ __device__ __forceinline__ void reservoir_scan(uint64_t *keys, uint32_t &cnt, ui
 // histogram, most significant byte first), then everything below it and everything equal to it is collected -- the
 // caller's final sort of those few keys settles the order and, among equal distances, the smaller ids.  Returns false
 // (nothing touched) when the ties at the k-th distance would not fit the reservoir; the reservoir scan handles that.
+__device__ __forceinline__ void wave_sync() {                      // orders this wave's LDS traffic for the compiler; the hardware keeps it in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// inclusive prefix sum over the 64 lanes by DPP (no LDS round trips: a scan by __shfl_up is six dependent ds_bpermute)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);       // row_shr:8: every row of 16 holds its own scan
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);       // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);       // row_bcast:31 into rows 2 and 3
+    return v;
+}
 // Bit pattern of the k-th smallest of n non-negative fp32 values held in registers (value e of thread t is element
 // t + e * THREADS; elements >= n are ignored): four passes of a 256-bin LDS histogram, most significant byte first.
 template <uint32_t THREADS, int VPT>
@@ -1111,19 +1125,21 @@ __device__ __forceinline__ uint32_t radix_kth(const uint32_t (&u)[VPT], uint32_t
         }
         if (run_len) atomicAdd(&hist[run_bin], run_len);
         __syncthreads();
-        if (tid < 16) {                                              // 16 partial sums of 16 bins each
-            uint32_t sum = 0;
-            for (int b = 0; b < 16; ++b) sum += hist[tid * 16 + b];
-            ctl[4 + tid] = sum;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t cum = 0, g = 0;
-            while (g < 15 && cum + ctl[4 + g] < need) cum += ctl[4 + g++];
-            uint32_t b = g * 16;
-            while (b < g * 16 + 15 && cum + hist[b] < need) cum += hist[b++];
-            ctl[0] = prefix | (b << (8 * pass));
-            ctl[1] = need - cum;                                     // rank of the wanted element inside the chosen bin
+        if (tid < 64) {                                              // the first wave finds the bin of the need-th value: a DPP scan over 4 bins per lane
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t incl = wave_incl_scan(h0 + h1 + h2 + h3);
+            const uint64_t hit = __ballot(incl >= need);
+            const int L = hit ? __builtin_ctzll(hit) : 63;           // (need <= number of matching values, so some lane qualifies)
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, L), b1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, L),
+                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)h2, L), b3 = (uint32_t)__builtin_amdgcn_readlane((int)h3, L);
+            uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (b0 + b1 + b2 + b3), bin = 4 * L;
+            if (cum + b0 < need) { cum += b0; ++bin;
+                if (cum + b1 < need) { cum += b1; ++bin;
+                    if (cum + b2 < need) { cum += b2; ++bin; } } }
+            if (tid == 0) {
+                ctl[0] = prefix | (bin << (8 * pass));
+                ctl[1] = need - cum;                                 // rank of the wanted element inside the chosen bin
+            }
         }
         __syncthreads();
         prefix = ctl[0]; need = ctl[1]; mask |= 0xFFu << (8 * pass);
@@ -1338,20 +1354,6 @@ __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) { select_one<THRE
 // A workgroup takes four queries; if any of them cannot go this way (candidate list overflowed -> exact rescan, first or
 // last chunk) the whole workgroup runs select_one() on its four queries in turn.
 constexpr uint32_t MW_VPT = SEL_CAP / 64;
-__device__ __forceinline__ void wave_sync() {                      // orders this wave's LDS traffic for the compiler; the hardware keeps it in order
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// inclusive prefix sum over the 64 lanes by DPP (no LDS round trips: a scan by __shfl_up is six dependent ds_bpermute)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);       // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);       // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);       // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);       // row_shr:8: every row of 16 holds its own scan
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);       // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);       // row_bcast:31 into rows 2 and 3
-    return v;
-}
 // The k smallest of n unique 64-bit keys held by one wave (slot e of lane l is element e * 64 + l < n; hi_at(e) / lo_at(e) yield
 // the distance word and the id word of its key) go to the state of query q, unordered; the k-th distance becomes the query's
 // threshold.  All tests run on the 32-bit halves (a pass over distance bytes never touches the ids).
