@@ -796,26 +796,6 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     const uint32_t q_valid = (uint32_t)(p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM);
     const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);
     char *const sB16_0 = smem, *const sB16_1 = smem + TN * PITCH;   // column tiles alternate between two buffers: ONE barrier per tile
-    // The query operand never changes during the walk: each wave keeps its fragments in registers (lane l: row l & 31 of each
-    // 32-row block, 8 consecutive k of every 16-deep step = 16 bytes of the bf16 row image; rows past the end re-read the last
-    // valid row -- their products land in accumulator rows the epilogue never emits)
-    bf16x8 afrag[MI][D / 16];
-    {
-        const uint16_t *abase = p.xq16 + q0 * (size_t)D;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const uint32_t r = wm + 32 * i + (lane & 31);
-            const uint16_t *row = abase + (r < q_valid ? r : q_valid - 1) * D + (lane >> 5) * 8;
-#pragma unroll
-            for (int ks = 0; ks < D / 16; ++ks) afrag[i][ks] = *reinterpret_cast<const bf16x8 *>(row + ks * 16);
-        }
-    }
-    float row_qn = 0.f, row_tau = -INFINITY;                        // rows past nq: nothing passes
-    if constexpr (FILTER) {
-        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
-        // the rows of the query tile are the same for every column tile: staged once
-        l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
-    }
     // a column tile is PIECES consecutive 16-byte pieces of the image (the allocation is padded by one tile of zero rows, so
     // the last tile of the base reads in bounds) and is copied as such by LDS-DMA (global_load_lds_dwordx4: no registers, no
     // ds_write): lane t moves pieces t, t + 256, ...; one wave-instruction fills 1 KiB of LDS from its wave-uniform base.
@@ -841,8 +821,30 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
+    // the first tile is requested BEFORE the query fragments and row thresholds are loaded: one round trip to memory for the
+    // prologue of a walk instead of two (a walk is 8 tiles of ~2 us; the serialised prologue was ~4 us of it)
     stage_b(ct0, sB16_0);
     if constexpr (!FILTER) fetch_bn(ct0);
+    // The query operand never changes during the walk: each wave keeps its fragments in registers (lane l: row l & 31 of each
+    // 32-row block, 8 consecutive k of every 16-deep step = 16 bytes of the bf16 row image; rows past the end re-read the last
+    // valid row -- their products land in accumulator rows the epilogue never emits)
+    bf16x8 afrag[MI][D / 16];
+    {
+        const uint16_t *abase = p.xq16 + q0 * (size_t)D;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const uint32_t r = wm + 32 * i + (lane & 31);
+            const uint16_t *row = abase + (r < q_valid ? r : q_valid - 1) * D + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) afrag[i][ks] = *reinterpret_cast<const bf16x8 *>(row + ks * 16);
+        }
+    }
+    float row_qn = 0.f, row_tau = -INFINITY;                        // rows past nq: nothing passes
+    if constexpr (FILTER) {
+        if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
+        // the rows of the query tile are the same for every column tile: staged once
+        l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the row half of the threshold k-step: lanes 0..31 carry (1, 1, 1, -r0, -r1, -r2, 0, 0) of their row for k = 0..7, lanes
