@@ -1732,10 +1732,16 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
         if (b16) {
-            // column tiles per workgroup: as many as keep every workgroup slot of the device (2 per CU) busy, at most 16
-            size_t group = nct * t.n_qtiles / (2 * (size_t)f->num_cus * 2);
-            static const size_t group_cap = getenv("PF_FLAT_GROUP_CAP") ? (size_t)atoi(getenv("PF_FLAT_GROUP_CAP")) : 8;   // experiments
-            group = group < 1 ? 1 : group > group_cap ? group_cap : group;
+            // Column tiles per workgroup: the launch should take the fewest whole rounds of resident workgroups (2 per CU) that walks of
+            // at most group_cap tiles allow, and fill them -- a walk pays a prologue and a flush (about three tiles' worth), and a
+            // round that is a quarter full takes as long as a full one.  (Before: two rounds whatever the chunk and walks of at most 8
+            // tiles; 16 k columns ran as 2 x 1 tile, 213 k as 3.25 rounds of 8.  Measured over the cap: 8 0.555, 16 0.537, 32 0.520,
+            // 64 0.514, 128 0.510 ms per search -- most chunks are then one round of workgroups that walk their whole share.)
+            static const size_t group_cap = getenv("PF_FLAT_GROUP_CAP") ? (size_t)atoi(getenv("PF_FLAT_GROUP_CAP")) : 64;   // experiments
+            const size_t per_round = 2 * f->num_cus / t.n_qtiles ? 2 * f->num_cus / t.n_qtiles : 1;       // column groups of one round
+            const size_t rounds = (nct + per_round * group_cap - 1) / (per_round * group_cap);
+            size_t group = (nct + per_round * rounds - 1) / (per_round * rounds);
+            group = group < 1 ? 1 : group;
             const size_t n_groups = (nct + group - 1) / group;
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
