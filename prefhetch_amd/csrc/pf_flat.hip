@@ -579,10 +579,25 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 struct Pend16 {
     static constexpr uint32_t CAP = 1112;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
     uint32_t id[CAP];                  // base row
-    uint32_t loc[CAP];                 // local query row; flush() adds the row-local index in the upper half
+    uint32_t loc[CAP];                 // local query row
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
 };
+
+#ifdef PF_FLAT_STAMPS        // experiments (tools/flat_stamps.py): s_memtime at the phase boundaries of the tile walk
+#define PF_FS_WGS 32
+#define PF_FS_TILES 16
+#define PF_FS_K 6
+__device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF_FS_K];
+#define PF_FSTAMP(k) do { if (fs_on && (tid & 63) == 0 && ct - ct0 < PF_FS_TILES) \
+    pf_flat_stamp_buf[(((blockIdx.x - 256) * 4 + (tid >> 6)) * PF_FS_TILES + (ct - ct0)) * PF_FS_K + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8];
+#define PF_FLSTAMP(k) do { if (p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS && (tid & 63) == 0) \
+    pf_flat_flush_stamp_buf[((blockIdx.x - 256) * 4 + (tid >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PF_FSTAMP(k) do { } while (0)
+#define PF_FLSTAMP(k) do { } while (0)
+#endif
 
 // The verdict words of MT tiles (surv[u][jj]: tile ct_base + u, column block jj; bit 31 - s = accumulator row s of this lane)
 // are decoded here, once per MT tiles, by the lane that owns them: each survivor takes a slot of the list and its index
@@ -604,7 +619,9 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
     for (int u = 0; u < MT; ++u)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
+    PF_FLSTAMP(0);
     while (__syncthreads_or(left != 0)) {                         // (the barrier: the list is empty, every row count zero)
+        PF_FLSTAMP(1);
         uint32_t slot = left ? atomicAdd(&pd.n, left) : 0u;
         uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
         take = left < take ? left : take;
@@ -621,12 +638,15 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                     const int s = 31 - b, r = s & 15;
                     const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                     pd.id[slot] = id;
-                    pd.loc[slot] = lrow | (atomicAdd(&pd.rcnt[lrow], 1u) << 16);
+                    pd.loc[slot] = lrow;
+                    atomicAdd(&pd.rcnt[lrow], 1u);                      // no return value: the position inside the row is drawn when the key is written
                     ++slot; --take;
                 }
                 surv[u][jj] = m;
             }
+        PF_FLSTAMP(2);
         __syncthreads();
+        PF_FLSTAMP(3);
         const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
         if (approx) {                                                 // workgroup-uniform
             // inexact operands: the distance of a survivor is the k-ordered fp32 chain over the fp32 rows -- what the fp32 tiles
@@ -649,7 +669,7 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             }
             __syncthreads();
             for (uint32_t e = tid; e < n; e += 256) {
-                const uint32_t loc = pd.loc[e], id = pd.id[e], row = loc & 0xFFFFu, pos = pd.rbase[row] + (loc >> 16);
+                const uint32_t row = pd.loc[e], id = pd.id[e], pos = atomicAdd(&pd.rbase[row], 1u);
                 if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
                 const float4 *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
                 float acc = 0.f;
@@ -687,17 +707,19 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             for (int u = 0; u < U; ++u) {
                 const uint32_t e = e0 + u * G + g < n ? e0 + u * G + g : n - 1;     // idle groups of the last pass repeat the last survivor
                 loc[u] = pd.loc[e]; id[u] = pd.id[e];
-                va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + (loc[u] & 0xFFFFu)) * (size_t)D + 8 * l);
+                va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + loc[u]) * (size_t)D + 8 * l);
                 vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
                 bnv[u] = p.bn[id[u]];
             }
             if (e0 == 0) {                                            // workgroup-uniform
+                PF_FLSTAMP(4);
                 if (tid < 128) {
                     const uint32_t c = pd.rcnt[tid];
                     pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
                     pd.rcnt[tid] = 0;
                 }
                 __syncthreads();
+                PF_FLSTAMP(5);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -712,28 +734,21 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
                 if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
-                const uint32_t row = loc[u] & 0xFFFFu, pos = pd.rbase[row] + (loc[u] >> 16);
-                if (l == 0 && e0 + u * G + g < n && pos < p.cap) {
-                    const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
-                    p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id[u]);
+                if (l == 0 && e0 + u * G + g < n) {                  // the position inside the row's reserved range: a running count in LDS
+                    const uint32_t row = loc[u], pos = atomicAdd(&pd.rbase[row], 1u);
+                    if (pos < p.cap) {
+                        const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
+                        p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id[u]);
+                    }
                 }
             }
         }
+        PF_FLSTAMP(6);
         __syncthreads();
         if (tid == 0) pd.n = 0;
     }
+    PF_FLSTAMP(7);
 }
-
-#ifdef PF_FLAT_STAMPS        // experiments (tools/flat_stamps.py): s_memtime at the phase boundaries of the tile walk
-#define PF_FS_WGS 32
-#define PF_FS_TILES 16
-#define PF_FS_K 6
-__device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF_FS_K];
-#define PF_FSTAMP(k) do { if (fs_on && (tid & 63) == 0 && ct - ct0 < PF_FS_TILES) \
-    pf_flat_stamp_buf[(((blockIdx.x - 2048) * 4 + (tid >> 6)) * PF_FS_TILES + (ct - ct0)) * PF_FS_K + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define PF_FSTAMP(k) do { } while (0)
-#endif
 
 // FILTER epilogue of the bf16 tiles: the accumulators hold the filter value (above), a distance can pass only where the sign
 // bit is clear.  Row s = 16 i + r of a lane ends up in bit 31 - s of the lane's word for its column block.  That is all a tile
@@ -875,7 +890,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         }
     }
 #ifdef PF_FLAT_STAMPS
-    const bool fs_on = FILTER && p.nb_count >= 400000 && blockIdx.x >= 2048 && blockIdx.x < 2048 + PF_FS_WGS;
+    const bool fs_on = FILTER && p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS;
 #endif
     // MT tiles between two flushes: their verdict words stay in registers (a 16-register vector written through a wave-uniform
     // index: the tile loop stays rolled -- unrolled MT times it ran out of registers, and a single scratch reload inside the
@@ -1858,5 +1873,9 @@ pf_status pf_gather_rows(pf_flat *f, const int64_t *ids, size_t n_ids, float *ou
 extern "C" int pf_flat_debug_stamps(unsigned long long *out, size_t n) {
     const size_t have = sizeof(pf::pf_flat_stamp_buf) / 8;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::pf_flat_stamp_buf), (n < have ? n : have) * 8);
+}
+extern "C" int pf_flat_debug_flush_stamps(unsigned long long *out, size_t n) {
+    const size_t have = sizeof(pf::pf_flat_flush_stamp_buf) / 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::pf_flat_flush_stamp_buf), (n < have ? n : have) * 8);
 }
 #endif
