@@ -301,6 +301,26 @@ def test_step_captured_in_a_hip_graph(pf, capsys):
         Dr, Ir = oracle.flat_l2_search(xb, hq, k)
         assert (I.cpu().numpy() == Ir).all() and (D.cpu().numpy() == Dr).all()
         assert (pf.to_host_u64(out) == o.ct_pt_mul(hct, hpt)).all()
+    # a batch (bf16 tiles fed by LDS-DMA, merges by a wave per query) captured the same way
+    nqb = 300
+    flat.reserve(nqb, k)
+    xqb = torch.empty((nqb, 128), dtype=torch.float32, device=dev)
+    xqb.copy_(torch.from_numpy(_sift_like(rng, nqb)))
+    with torch.cuda.stream(side):
+        flat.search(xqb, k)
+    torch.cuda.synchronize()
+    gb = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gb):
+        Db, Ib = flat.search(xqb, k)
+    for _ in range(2):
+        hq = _sift_like(rng, nqb)
+        xqb.copy_(torch.from_numpy(hq))
+        gb.replay()
+        torch.cuda.synchronize()
+        Dr, Ir = oracle.flat_l2_search(xb, hq[:6], k)
+        assert (Ib[:6].cpu().numpy() == Ir).all() and (Db[:6].cpu().numpy() == Dr).all()
+        De, Ie = flat.search(xqb, k)
+        assert (Ib == Ie).all() and (Db == De).all()
     # launch-bound case: one query against 1M rows, eager against replay
     big = pf.FlatL2(_sift_like(rng, 1_000_000), dev)
     big.reserve(1, 200)
