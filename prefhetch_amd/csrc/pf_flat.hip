@@ -606,7 +606,7 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8];
 // key.  A list too small for everything (dense early chunks) is worked off in rounds: the words not yet decoded stay in
 // the registers.  Barriers inside: call from all threads.
 #ifndef PF_FLUSH_U
-#define PF_FLUSH_U 4
+#define PF_FLUSH_U 6
 #endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
