@@ -591,9 +591,9 @@ struct Pend16 {
 __device__ unsigned long long pf_flat_stamp_buf[PF_FS_WGS * 4 * PF_FS_TILES * PF_FS_K];
 #define PF_FSTAMP(k) do { if (fs_on && (tid & 63) == 0 && ct - ct0 < PF_FS_TILES) \
     pf_flat_stamp_buf[(((blockIdx.x - 256) * 4 + (tid >> 6)) * PF_FS_TILES + (ct - ct0)) * PF_FS_K + (k)] = __builtin_readcyclecounter(); } while (0)
-__device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8];
-#define PF_FLSTAMP(k) do { if (p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS && (tid & 63) == 0) \
-    pf_flat_flush_stamp_buf[((blockIdx.x - 256) * 4 + (tid >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];      // [workgroup][wave][flush of the walk][stamp]
+#define PF_FLSTAMP(k) do { if (p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS && (tid & 63) == 0 && flush_no < 8) \
+    pf_flat_flush_stamp_buf[(((blockIdx.x - 256) * 4 + (tid >> 6)) * 8 + flush_no) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PF_FSTAMP(k) do { } while (0)
 #define PF_FLSTAMP(k) do { } while (0)
@@ -610,7 +610,9 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8];
 #endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
-                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid) {
+                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid,
+                                             uint32_t flush_no = 0) {
+    (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
     const int lane = tid & 63;
@@ -631,8 +633,9 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 uint32_t m = surv[u][jj];
+                if (__ballot(m != 0) == 0) continue;                  // wave-uniform: nothing in this word anywhere in the wave
                 const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * 128 + wn + 32 * jj + (lane & 31));
-                while (m && take) {
+                auto park = [&]() {                                   // highest set bit of m: one survivor
                     const int b = 31 - __builtin_clz(m);
                     m &= ~(1u << b);
                     const int s = 31 - b, r = s & 15;
@@ -641,7 +644,12 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                     pd.loc[slot] = lrow;
                     atomicAdd(&pd.rcnt[lrow], 1u);                      // no return value: the position inside the row is drawn when the key is written
                     ++slot; --take;
-                }
+                };
+                // a lane rarely holds more than one bit of a word: the first one without a loop (a loop iteration costs a vector
+                // compare -> exec round trip; sixteen word loops were 5 400 of a flush's 15 000 cycles), the rest -- if any lane of
+                // the wave has one -- in the loop
+                if (m && take) park();
+                if (__ballot(m && take)) while (m && take) park();
                 surv[u][jj] = m;
             }
         PF_FLSTAMP(2);
@@ -721,6 +729,10 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 __syncthreads();
                 PF_FLSTAMP(5);
             }
+            // positions inside the rows' reserved ranges: running counts in LDS, all U requested before the first is used
+            uint32_t pos[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pos[u] = (l == 0 && e0 + u * G + g < n) ? atomicAdd(&pd.rbase[loc[u]], 1u) : ~0u;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float s = 0.f;
@@ -734,12 +746,10 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
                 if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
-                if (l == 0 && e0 + u * G + g < n) {                  // the position inside the row's reserved range: a running count in LDS
-                    const uint32_t row = loc[u], pos = atomicAdd(&pd.rbase[row], 1u);
-                    if (pos < p.cap) {
-                        const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
-                        p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id[u]);
-                    }
+                if (pos[u] < p.cap) {                                 // (~0 for idle lanes and groups)
+                    const uint32_t row = loc[u];
+                    const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
+                    p.cand[(q0 + row) * p.cap + pos[u]] = make_key(dist < 0.f ? 0.f : dist, id[u]);
                 }
             }
         }
@@ -975,7 +985,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
-                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid);
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }

@@ -43,14 +43,18 @@ for k in range(K - 1):
     print("  phase %d by tile:" % k, np.round((s[..., k + 1] - s[..., k]).mean(axis=(0, 1))).astype(int).tolist())
 print("by wave (mean): ", [[int((s[:, w, :, k + 1] - s[:, w, :, k]).mean()) for k in range(K - 1)] for w in range(4)])
 
-fb = np.zeros(WGS * 4 * 8, dtype=np.uint64)
+fb = np.zeros(WGS * 4 * 8 * 8, dtype=np.uint64)
 if hasattr(lib, "pf_flat_debug_flush_stamps") and lib.pf_flat_debug_flush_stamps(fb.ctypes.data_as(C.c_void_p), C.c_size_t(fb.size)) == 0:
-    f = fb.reshape(WGS * 4, 8).astype(np.int64)
-    f = f[f[:, 0] > 0]
+    fall = fb.reshape(WGS * 4, 8, 8).astype(np.int64)
     fn = ["entry -> first barrier (__syncthreads_or)", "slot reservation + decode of the verdict words", "barrier", "list -> row loads issued", "row reservations (global atomics) + barrier",
           "dot products, keys written", "last barrier, second __syncthreads_or, exit"]
-    print("last flush of the stamped waves (cycles):")
-    for k in range(7):
-        d = f[:, k + 1] - f[:, k]
-        print("  %-52s mean %7.0f  p50 %7.0f  max %7.0f" % (fn[k], d.mean(), np.median(d), d.max()))
-    print("  %-52s mean %7.0f" % ("whole flush", (f[:, 7] - f[:, 0]).mean()))
+    for no in (0, 1, 2):
+        f = fall[:, no]
+        f = f[f[:, 0] > 0]
+        if not len(f):
+            continue
+        print("flush %d of the walk, stamped waves (cycles):" % no)
+        for k in range(7):
+            d = f[:, k + 1] - f[:, k]
+            print("  %-52s mean %7.0f  p50 %7.0f  max %7.0f" % (fn[k], d.mean(), np.median(d), d.max()))
+        print("  %-52s mean %7.0f" % ("whole flush", (f[:, 7] - f[:, 0]).mean()))
