@@ -577,13 +577,10 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 // same tiles as a conservative filter -- margin 1.05 x 2^-8 (|x|^2 + |y|^2) on the thresholds, the survivors' distances by
 // the fp32 chain over the fp32 rows (flush) -- and fp32 tiles where that filter cannot help (k_l2_tile16, select_one).
 struct Pend16 {
-    static constexpr uint32_t RCAP = 112;     // verdict records of a wave between two flushes
-    static constexpr uint32_t CAP = 384;      // survivors per round of a flush (operands + rows + this struct fit twice into a CU's 160 KiB)
-    uint32_t rec[4][RCAP][3];          // per wave: {tiles since the last flush | lane << 8, verdict word of column block 0, of block 1}
+    static constexpr uint32_t CAP = 1112;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
     uint32_t id[CAP];                  // base row
     uint32_t loc[CAP];                 // local query row
     uint32_t rcnt[128], rbase[128];
-    uint32_t wcnt[2][4];               // records of each wave, by tile parity (read after the tile's barrier, rewritten before the next)
     uint32_t n;
 };
 
@@ -602,51 +599,59 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 #define PF_FLSTAMP(k) do { } while (0)
 #endif
 
-// A lane whose tile has a survivor leaves a RECORD -- (tile, lane, its two verdict words; bit 31 - s = accumulator row s) -- in its
-// wave's list (ballot + prefix count: no atomic, no loop, a dozen instructions per tile).  flush() turns the records into
-// survivors, every thread taking records of its own wave: slot in the survivor list and count per query row (LDS atomics), ONE
-// returning global atomic per row with survivors for its range of the candidate list, then sixteen lanes per survivor recompute
-// the dot product from the two 16-bit rows and the group's first lane writes the key.  More survivors than the list holds
-// (dense early chunks) are worked off in rounds: the bits not yet taken stay in the records.  Runs when a wave's record list could
-// overflow during the next tile, and at the end of the walk.  Barriers inside: call from all threads.
-// (Before: the words of 8 tiles in a register vector, decoded by sixteen per-lane loops per flush -- 5 900 of a flush's 17 000
-// cycles, flushes a third of the long chunk's time; phase stamps in tools/flat_stamps.py.)
+// The verdict words of MT tiles (surv[u][jj]: tile ct_base + u, column block jj; bit 31 - s = accumulator row s of this lane)
+// are decoded here, once per MT tiles, by the lane that owns them: each survivor takes a slot of the list and its index
+// within its query row (LDS atomics), a row with survivors reserves its range of the candidate list with ONE global atomic,
+// then sixteen lanes per survivor recompute the dot product from the two 16-bit rows and the group's first lane writes the
+// key.  A list too small for everything (dense early chunks) is worked off in rounds: the words not yet decoded stay in
+// the registers.  Barriers inside: call from all threads.
 #ifndef PF_FLUSH_U
 #define PF_FLUSH_U 6
 #endif
-template <int D>
-__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t ct_base, uint32_t parity,
-                                             int wm, int wn, bool approx, char *xstage, uint32_t q_valid, uint32_t flush_no = 0) {
+template <int D, int MT, int NJ>
+__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
+                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid,
+                                             uint32_t flush_no = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t n_rec = pd.wcnt[parity][wave];
-    PF_FLSTAMP(0);
-    for (;;) {                                                    // (entered behind a barrier: the records are complete, the survivor list is empty)
-        PF_FLSTAMP(1);
-        bool pending = false;
-        for (uint32_t r = lane; r < n_rec; r += 64) {
-            uint32_t *rec = pd.rec[wave][r];
-            const uint32_t info = rec[0], rl = info >> 8, u = info & 255u;
-            const uint32_t id0 = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * 128 + wn + (rl & 31));
+    const int lane = tid & 63;
+    uint32_t left = 0;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                uint32_t m = rec[1 + jj];
-                while (m) {
-                    const uint32_t slot = atomicAdd(&pd.n, 1u);
-                    if (slot >= Pend16::CAP) { pending = true; break; }        // this round's list is full: the bit stays for the next round
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
+    PF_FLSTAMP(0);
+    while (__syncthreads_or(left != 0)) {                         // (the barrier: the list is empty, every row count zero)
+        PF_FLSTAMP(1);
+        uint32_t slot = left ? atomicAdd(&pd.n, left) : 0u;
+        uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
+        take = left < take ? left : take;
+        left -= take;
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                uint32_t m = surv[u][jj];
+                if (__ballot(m != 0) == 0) continue;                  // wave-uniform: nothing in this word anywhere in the wave
+                const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * 128 + wn + 32 * jj + (lane & 31));
+                auto park = [&]() {                                   // highest set bit of m: one survivor
                     const int b = 31 - __builtin_clz(m);
                     m &= ~(1u << b);
-                    const int sr = 31 - b, rr = sr & 15;
-                    const uint32_t lrow = (uint32_t)(wm + 2 * (sr & 16) + (rr & 3) + 8 * (rr >> 2) + 4 * (rl >> 5));
-                    pd.id[slot] = id0 + 32 * jj;
+                    const int s = 31 - b, r = s & 15;
+                    const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                    pd.id[slot] = id;
                     pd.loc[slot] = lrow;
                     atomicAdd(&pd.rcnt[lrow], 1u);                      // no return value: the position inside the row is drawn when the key is written
-                }
-                rec[1 + jj] = m;
+                    ++slot; --take;
+                };
+                // a lane rarely holds more than one bit of a word: the first one without a loop (a loop iteration costs a vector
+                // compare -> exec round trip; sixteen word loops were 5 400 of a flush's 15 000 cycles), the rest -- if any lane of
+                // the wave has one -- in the loop
+                if (m && take) park();
+                if (__ballot(m && take)) while (m && take) park();
+                surv[u][jj] = m;
             }
-        }
         PF_FLSTAMP(2);
         __syncthreads();
         PF_FLSTAMP(3);
@@ -696,7 +701,6 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             }
             __syncthreads();
             if (tid == 0) pd.n = 0;
-            if (!__syncthreads_or(pending)) break;
             continue;
         }
         // U survivors per group and pass: their rows are requested first, and in the first pass the per-row reservations (a
@@ -752,7 +756,6 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
         PF_FLSTAMP(6);
         __syncthreads();
         if (tid == 0) pd.n = 0;
-        if (!__syncthreads_or(pending)) break;                        // (also the barrier behind which the list is empty again)
     }
     PF_FLSTAMP(7);
 }
@@ -775,6 +778,9 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
     }
 }
 
+#ifndef PF_FLAT_MT
+#define PF_FLAT_MT 8
+#endif
 template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
 __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = GeoBatch;
@@ -896,9 +902,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #ifdef PF_FLAT_STAMPS
     const bool fs_on = FILTER && p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS;
 #endif
-    uint32_t wrec = 0, tsf = 0, flush_base = ct0, n_flush = 0;       // records of this wave, tiles since the last flush, its first tile (wave-uniform)
+    // MT tiles between two flushes: their verdict words stay in registers (a 16-register vector written through a wave-uniform
+    // index: the tile loop stays rolled -- unrolled MT times it ran out of registers, and a single scratch reload inside the
+    // loop makes hipcc wait for vmcnt(0), i.e. for the LDS-DMA of the next tile, before the matrix work)
+    constexpr int MT = PF_FLAT_MT;
+    using survx = __attribute__((ext_vector_type(MT * NJ))) uint32_t;
+    survx sv;
+#pragma unroll
+    for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
     for (uint32_t ct = ct0; ct < ct1; ++ct) {
-        const uint32_t cur = (ct - ct0) & 1u;
+        const uint32_t u = (ct - ct0) % MT, cur = (ct - ct0) & 1u;
         char *const buf_cur = cur ? sB16_1 : sB16_0, *const buf_nxt = cur ? sB16_0 : sB16_1;
         PF_FSTAMP(0);
         if (ct + 1 < ct1) stage_b(ct + 1, buf_nxt);                   // in flight under this tile's matrix work and epilogue
@@ -954,17 +967,8 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         if constexpr (FILTER) {
             uint32_t s1[NJ];
             l2_tile_verdicts16<GEO>(acc, col_ok, s1);
-            // a lane with a survivor leaves a record in its wave's list: position by ballot and prefix count
-            const bool any = (s1[0] | s1[NJ - 1]) != 0;
-            const uint64_t hit = __ballot(any);
-            if (hit) {                                                  // wave-uniform
-                if (any) {
-                    uint32_t *rec = pend.rec[wave][wrec + (uint32_t)__popcll(hit & ((1ull << lane) - 1))];
-                    rec[0] = tsf | ((uint32_t)lane << 8); rec[1] = s1[0]; rec[2] = s1[NJ - 1];
-                }
-                wrec += (uint32_t)__popcll(hit);
-            }
-            if (lane == 0) pend.wcnt[cur][wave] = wrec;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj];   // wave-uniform index: v_movreld
             PF_FSTAMP(4);
         } else {
             // q0 made opaque per tile: otherwise hipcc hoists the row addresses of the slab stores out of the tile loop
@@ -976,16 +980,15 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         __syncthreads();                                                // the tile's one barrier: the other buffer is complete
         PF_FSTAMP(5);
         if constexpr (FILTER) {
-            // flush when a wave's list might not hold the records of one more tile (64), at the end of the walk, or when the tile
-            // counter of a record would wrap -- decided on the counts all waves published before the barrier: workgroup-uniform
-            uint32_t most = pend.wcnt[cur][0];
+            if (u == MT - 1 || ct + 1 == ct1) {                         // workgroup-uniform
+                uint32_t surv[MT][NJ];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) most = pend.wcnt[cur][w] > most ? pend.wcnt[cur][w] : most;
-            if (most + 64 > Pend16::RCAP || ct + 1 == ct1 || tsf == 255) {
+                for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
-                if (most) pend16_flush<D>(p, pend, stage, q0, tid, flush_base, cur, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, n_flush);
-                ++n_flush; wrec = 0; tsf = 0; flush_base = ct + 1;
-            } else ++tsf;
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, (ct - ct0) / MT);
+#pragma unroll
+                for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
+            }
         }
     }
 }
