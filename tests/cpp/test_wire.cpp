@@ -11,6 +11,7 @@
 
 #include "client_lib.h"
 #include "http.h"
+#include "pir.h"
 #include "wire.h"
 
 static int failures = 0;
@@ -116,6 +117,34 @@ static int selftest() {
         std::vector<float> cs; std::vector<faiss_idx_t> ci; std::array<size_t, NQUERY> ls;
         std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> query{};
         EXPECT(throws<std::runtime_error>([&] { get_coarse_scores(few, query, cs, ci, ls); }));   // fewer than NPROBE centroids
+    }
+    // private retrieval (include/client/pir.h): the host-side arithmetic -- layout, query encoding, row decoding -- needs no device
+    {
+        const pir::Layout lay = pir::Layout::make(8192, 128, 10000);
+        EXPECT(lay.rows_per_poly == 32 && lay.n_polys == 313 && lay.levels == 9 && lay.poly_of(9999) == 312 && lay.slot_of(9999) == 15);
+        EXPECT(pir::Layout::make(8192, 128, 1).levels == 0 && pir::Layout::make(8192, 128, 33).levels == 1 && pir::Layout::make(8192, 64, 8192u * 64).levels == 13);
+        EXPECT(throws<std::invalid_argument>([] { pir::Layout::make(8192, 128, 8192u * 32 + 1); }));   // more than N polynomials
+        EXPECT(throws<std::invalid_argument>([] { pir::Layout::make(1024, 1024, 4); }));              // a row does not fit a polynomial
+        const std::vector<uint32_t> elts = pir::galois_elements(8192, 9);
+        EXPECT(elts.size() == 9 && elts[0] == 8193 && elts[1] == 4097 && elts[8] == 33);
+        std::vector<uint64_t> plain(8192);
+        pir::encode_query(lay, 65537, 9999, plain.data());
+        uint64_t nonzero = 0, at = 0;
+        for (size_t i = 0; i < plain.size(); ++i) if (plain[i]) { ++nonzero; at = i; }
+        EXPECT(nonzero == 1 && at == 312 && plain[at] * 512 % 65537 == 1);                              // 2^-9 mod t at the row's polynomial
+        EXPECT(throws<std::out_of_range>([&] { pir::encode_query(lay, 65537, 10000, plain.data()); }));
+        EXPECT(throws<std::invalid_argument>([&] { pir::encode_query(lay, 65536, 0, plain.data()); }));   // even modulus: 2 is not invertible
+        // a row as the server packs it (two 16-bit halves per float) comes back bit for bit, -0.0f and a NaN pattern included
+        float row[128], back[128];
+        for (int i = 0; i < 128; ++i) row[i] = (float)(i * 37 % 101) / 7.0f - 5.0f;
+        row[3] = -0.0f;
+        const uint32_t nan_bits = 0x7FC12345u;
+        std::memcpy(&row[4], &nan_bits, 4);
+        std::fill(plain.begin(), plain.end(), 0);
+        const size_t c0 = (size_t)lay.slot_of(9999) * 256;
+        for (int i = 0; i < 128; ++i) { uint32_t b; std::memcpy(&b, &row[i], 4); plain[c0 + 2 * i] = b & 0xFFFF; plain[c0 + 2 * i + 1] = b >> 16; }
+        pir::decode_row(lay, plain.data(), 9999, back);
+        EXPECT(std::memcmp(row, back, sizeof row) == 0);
     }
     std::printf(failures ? "selftest: %d failure(s)\n" : "selftest: ok\n", failures);
     return failures ? 1 : 0;
