@@ -119,27 +119,49 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ct
 template <class G, class A>
 struct RowsLoader {
     const float *xb; const int64_t *ids; size_t nb; uint32_t d, rows; uint64_t q;
-    // value of row j, element i (negated for the wrap-around of row 0); `live` false = empty coefficient
-    __device__ __forceinline__ typename A::V value(bool live, bool wrap, uint32_t j, uint32_t i) const {
-        float v = 0.f;
-        if (live) {
-            const int64_t id = ids[j];
-            if (id >= 0 && (size_t)id < nb) v = rintf(xb[(size_t)id * d + i]);
+    // Register k holds row j[k], element i[k] (negated for the wrap-around of row 0; `live` false = empty coefficient).  The loads go
+    // out in two batches -- all row ids, then all values -- from addresses that are always valid (an empty coefficient reads row
+    // 0 / id 0 and discards it): written as "if (live) { id = ids[j]; if (in range) v = xb[...]; }" per register, hipcc waited
+    // for every one of the 2 x R loads on its own (s_waitcnt vmcnt(0) behind each: 64 serialised round trips per thread).
+    __device__ __forceinline__ void fill(typename A::V (&r)[G::R], const bool (&live)[G::R], const bool (&wrap)[G::R], const uint32_t (&j)[G::R],
+                                         const uint32_t (&i)[G::R]) const {
+        int64_t id[G::R];
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) id[k] = ids[live[k] ? j[k] : 0u];
+        float v[G::R];
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) {
+            const bool ok = live[k] && id[k] >= 0 && (size_t)id[k] < nb;
+            v[k] = xb[ok ? (size_t)id[k] * d + i[k] : 0];
+            if (!ok) v[k] = 0.f;
         }
-        if (wrap) v = -v;
-        const int64_t iv = (int64_t)v;
-        return A::from_u64(iv >= 0 ? (uint64_t)iv : q - (uint64_t)(-iv));
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) {
+            float w = rintf(v[k]);
+            if (wrap[k]) w = -w;
+            const int64_t iv = (int64_t)w;
+            r[k] = A::from_u64(iv >= 0 ? (uint64_t)iv : q - (uint64_t)(-iv));
+        }
     }
     __device__ __forceinline__ void operator()(typename A::V (&r)[G::R], int tid) const {
+        bool live[G::R], wrap[G::R];
+        uint32_t j[G::R], i[G::R];
+        if (nb == 0 || rows == 0) {                              // nothing to read from (workgroup-uniform)
+#pragma unroll
+            for (int k = 0; k < G::R; ++k) r[k] = A::from_u64(0);
+            return;
+        }
         if (G::T % d == 0) {                                     // workgroup-uniform; d then divides N as well
             // jj = ceil(c / d) advances by T/d per register and i = jj*d - c does not depend on the register: one division
             // per thread.  jj == N/d is row 0 negated (its i equals N - c), jj in [rows, N/d) is empty.
-            const uint32_t jj0 = ((uint32_t)tid + d - 1) / d, i = jj0 * d - (uint32_t)tid, step = G::T / d;
+            const uint32_t jj0 = ((uint32_t)tid + d - 1) / d, i0 = jj0 * d - (uint32_t)tid, step = G::T / d;
 #pragma unroll
             for (int k = 0; k < G::R; ++k) {
                 const uint32_t jj = jj0 + (uint32_t)(G::koff(0, k) / G::T) * step;
-                const bool wrap = jj == G::N / d;
-                r[k] = value(wrap || jj < rows, wrap, wrap ? 0u : jj, i);
+                wrap[k] = jj == G::N / d;
+                live[k] = wrap[k] || jj < rows;
+                j[k] = wrap[k] ? 0u : jj;
+                i[k] = i0;
             }
         } else {
             // any d (the criterion of k_pack_rows): row jj = ceil(c / d) while jj < rows, else the wrap-around of row 0
@@ -147,10 +169,14 @@ struct RowsLoader {
 #pragma unroll
             for (int k = 0; k < G::R; ++k) {
                 const uint32_t c = (uint32_t)(G::koff(0, k) + tid), jj = (c + d - 1) / d;
-                const bool row = jj < rows, wrap = !row && (uint32_t)G::N - c < d;
-                r[k] = value(row || wrap, wrap, row ? jj : 0u, row ? jj * d - c : (uint32_t)G::N - c);
+                const bool row = jj < rows;
+                wrap[k] = !row && (uint32_t)G::N - c < d;
+                live[k] = row || wrap[k];
+                j[k] = row ? jj : 0u;
+                i[k] = row ? jj * d - c : (uint32_t)G::N - c;
             }
         }
+        fill(r, live, wrap, j, i);
     }
 };
 
