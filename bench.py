@@ -440,10 +440,14 @@ def main():
             ctx.ntt_forward_(ctn)
             ctx.ct_pt_mul_fanout(ctn, ptb, fan, out=res, flags=2)          # IN_NTT
 
-        def fused_kernel():                                                 # what Server::preciseSearchEncrypted runs
+        def fused_kernel():
             ctx.pack_rows(flat, ids, out=ptb, ntt=True)                     # packing inside the forward transform
             ctx.ntt_forward(ct, out=ctn)                                    # out of place: the caller's ciphertexts stay as they are
             ctx.ct_pt_mul_fanout(ctn, ptb, fan, out=res, flags=2)
+
+        def one_kernel():                                                   # what Server::preciseSearchEncrypted runs
+            ctx.ntt_forward(ct, out=ctn)                                    # out of place: the caller's ciphertexts stay as they are
+            ctx.ct_rows_mul(ctn, flat, ids, fan, out=res)                   # rows -> plaintext -> NTT -> x both components -> inverse NTT
 
         def timed(fn, reps=5):
             fn()
@@ -455,11 +459,17 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
 
-        ms_three, ms_enc = timed(three_kernels), timed(fused_kernel)
+        ms_three, ms_two, ms_enc = timed(three_kernels), timed(fused_kernel), timed(one_kernel)
+        fused_kernel()
+        res_two = res.clone()
+        one_kernel()
         enc_round = {"ms": ms_enc, "queries_per_s": B / (ms_enc * 1e-3), "ct_x_pt_per_query": fan, "candidates_per_query": TOPK,
-                     "unfused_ms": ms_three,
-                     "note": "pf_pack_rows_ntt (rows packed in registers -> forward NTT) + one NTT of the query ciphertexts + fused dyadic / "
-                             "inverse NTT with ciphertext fan-out; unfused_ms = with pack and NTT(pt) as separate kernels"}
+                     "plaintexts_in_memory_ms": ms_two, "unfused_ms": ms_three, "bit_identical_to_plaintexts_in_memory": bool(torch.equal(res, res_two)),
+                     "note": "one NTT of the query ciphertexts + pf_ct_rows_mul (candidate rows -> plaintext in registers -> forward NTT -> "
+                             "x both ciphertext components -> inverse NTTs, one workgroup per product and limb); plaintexts_in_memory_ms = "
+                             "pf_pack_rows_ntt + pf_ct_pt_mul_fanout (NTT-form plaintexts written and read back); unfused_ms = pack, "
+                             "NTT(pt), copy, NTT(ct), products as separate kernels"}
+        del res_two
         del ids, ptb, ctn, res
 
     ms_a = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))

@@ -146,6 +146,15 @@ pf_status pf_pack_rows(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size
 pf_status pf_pack_rows_ntt(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly,
                            uint64_t *out, pf_stream stream);
 
+/* The server side of the encrypted precise search in ONE kernel: out[b] = ct[b / fanout] x pack(ids[b]), b < B, with the
+ * plaintext of product b packed from the base rows (pf_pack_rows), transformed and multiplied into both components of
+ * its ciphertext inside one workgroup per (product, limb) -- the plaintexts never exist in memory, in either form.
+ * ct_ntt [ceil(B / fanout)][2][L][N] in NTT form (pf_ntt_forward_to of the query ciphertexts), ids [B][rows_per_poly]
+ * (device), out [B][2][L][N] coefficient form, must not alias ct_ntt.  Bit for bit pf_pack_rows_ntt followed by
+ * pf_ct_pt_mul_fanout(..., PF_CTPT_IN_NTT).  N <= 16384.  No allocation, no synchronisation. */
+pf_status pf_ct_rows_mul(pf_ctx *ctx, const uint64_t *ct_ntt, const pf_flat *idx, const int64_t *ids, size_t B, uint32_t rows_per_poly,
+                         uint32_t fanout, uint64_t *out, pf_stream stream);
+
 /* ---- plaintext distance stages ---------------------------------------------------------------- */
 /* faiss::IndexFlatL2(d) + add(nb, xb): copies the base matrix [nb][d] fp32 (host or device pointer)
  * into HBM and precomputes row norms.  Blocking. */

@@ -181,6 +181,25 @@ class RnsContext:
         check(fn(self._h, flat._h, pi, n_polys, rows, po, _stream(self.device)), "pf_pack_rows_ntt" if ntt else "pf_pack_rows")
         return out
 
+    def ct_rows_mul(self, ct_ntt, flat, ids, fanout, out=None):
+        """out[b] = ct_ntt[b // fanout] x pack(ids[b]) in one kernel (pack_rows(ntt=True) + ct_pt_mul_fanout(IN_NTT), bit for
+        bit, without the plaintexts ever existing in memory): ct_ntt [ceil(B/fanout),2,L,N] NTT form, ids [B, rows_per_poly]
+        -> out [B,2,L,N] coefficient form."""
+        if ids.dim() != 2:
+            raise ValueError("ids must be [B, rows_per_poly]")
+        if int(fanout) < 1:
+            raise ValueError("fanout must be at least 1")
+        B, rows = ids.shape
+        if ct_ntt.numel() != -(-B // int(fanout)) * 2 * self.L * self.N:
+            raise ValueError("ct_ntt must hold ceil(B / fanout) ciphertexts")
+        if out is None:
+            out = torch.empty((B, 2, self.L, self.N), dtype=torch.int64, device=self.device)
+        if out.numel() != B * 2 * self.L * self.N:
+            raise ValueError("out must hold B ciphertexts")
+        pc, pi, po = (_req(t, torch.int64, self.device_index, n) for t, n in ((ct_ntt, "ct_ntt"), (ids, "ids"), (out, "out")))
+        check(lib.pf_ct_rows_mul(self._h, pc, flat._h, pi, B, rows, int(fanout), po, _stream(self.device)), "pf_ct_rows_mul")
+        return out
+
     def key_switch_(self, target, ksk, ct):
         """This context holds the key moduli (special prime last).  target [B,D,N], ksk [D,2,D+1,N] (NTT form),
         ct [B,2,D,N]: the switched polynomial is added into ct in place."""

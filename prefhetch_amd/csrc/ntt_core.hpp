@@ -1142,4 +1142,31 @@ PF_HD void body_ntt_fwd_from(const A &ar, const typename A::Tw *__restrict__ tw,
     store_last_staged<G>(o, dst, tid, lds, sync);
 }
 
+// Encrypted precise search in one pass (pf_ct_rows_mul): the plaintext is produced by `load` (as in body_ntt_fwd_from),
+// transformed ONCE and kept in registers while both components of the ciphertext (NTT form) are multiplied by it and
+// transformed back -- the NTT-form plaintext never exists in memory.  64 more live registers than body_ctpt: budgeted
+// for 2 workgroups per CU instead of 3.
+template <class G, class A, class Loader, class Sync>
+PF_HD void body_rows_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const typename A::Tw *__restrict__ itw, const Loader &load,
+                          const uint64_t *ct0, const uint64_t *ct1, uint64_t *out0, uint64_t *out1, typename A::V *lds, int tid, Sync &&sync) {
+    using V = typename A::V;
+    V pv[G::R];
+    load(pv, tid);
+    fwd_all<G, A, true>(pv, ar, tw, lds, tid, sync);
+    canon_all<G, A>(pv, ar);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        V r[G::R];
+        PassTw<G, A, G::LAST> tl;
+        load_last<G, A>(r, c ? ct1 : ct0, tid);
+        tl.load(itw, tid);
+        dyadic_all<G, A, false>(r, pv, ar);
+        PF_LAUNDER(tid);
+        inv_all<G, A>(r, ar, tl, itw, lds, tid, sync);
+        uint64_t *out = c ? out1 : out0;
+#pragma unroll
+        for (int k = 0; k < G::R; ++k) (out + G::koff(0, k))[tid] = A::to_u64(ar.canon_small(r[k]));
+    }
+}
+
 }  // namespace pf

@@ -292,6 +292,23 @@ pf_status pf_pack_rows_ntt(pf_ctx *c, const pf_flat *idx, const int64_t *ids, si
     return run_ntt_like(c, 4, 0, a, n_polys * (size_t)c->L, stream);
 }
 
+pf_status pf_ct_rows_mul(pf_ctx *c, const uint64_t *ct_ntt, const pf_flat *idx, const int64_t *ids, size_t B, uint32_t rows_per_poly,
+                         uint32_t fanout, uint64_t *out, pf_stream stream) {
+    if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");
+    if (B == 0) return PF_OK;
+    if (!ct_ntt || !ids || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (fanout == 0) return fail(PF_ERR_INVALID_ARG, "fanout must be at least 1");
+    if (ct_ntt == out) return fail(PF_ERR_INVALID_ARG, "out must not alias the ciphertexts");
+    if (c->logn > 14) return fail(PF_ERR_UNSUPPORTED, "pf_ct_rows_mul: N <= 16384 (use pf_pack_rows_ntt + pf_ct_pt_mul_fanout above that)");
+    size_t nb = 0; uint32_t d = 0; int dev = 0;
+    const float *xb = flat_base_device(idx, &nb, &d, &dev);
+    if (dev != c->device) return fail(PF_ERR_INVALID_ARG, "context and index live on different devices");
+    if (rows_per_poly == 0 || (size_t)rows_per_poly * d > c->N) return fail(PF_ERR_INVALID_ARG, "rows_per_poly must be in [1, N / d]");
+    const size_t n_ct = (B + fanout - 1) / fanout, groups = n_ct * (size_t)c->L;
+    NttArgs a{c->d_limbs, c->d_tables, ct_ntt, out, nullptr, B, c->L, 0u, 0u, fanout, xb, ids, nb, d, rows_per_poly};
+    return run_ntt_like(c, 5, 0, a, (groups + 7) / 8 * 8 * fanout, stream);   // 8 XCD streams x groups x fanout products
+}
+
 pf_status pf_pack_rows(pf_ctx *c, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly, uint64_t *out,
                        pf_stream stream) {
     if (!c || !idx) return fail(PF_ERR_INVALID_ARG, "null context or index");

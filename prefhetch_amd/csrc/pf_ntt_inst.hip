@@ -17,6 +17,10 @@ void launch_family(int op, int flags, const NttArgs &a, unsigned nblocks, hipStr
     if (op == 1) { hipLaunchKernelGGL((k_ntt<LOGN, A, true>), grid, block, 0, s, a); return; }
     if (op == 3) { hipLaunchKernelGGL((k_ks_ntt<LOGN, A>), grid, block, 0, s, a); return; }
     if (op == 4) { hipLaunchKernelGGL((k_rows_ntt<LOGN, A>), grid, block, 0, s, a); return; }
+    if (op == 5) {
+        if constexpr (Geo<LOGN>::R <= 32) hipLaunchKernelGGL((k_rows_ctpt<LOGN, A>), grid, block, 0, s, a);   // host refuses the larger degrees
+        return;
+    }
     switch (flags & 7) {
 #define PF_CASE(F) case F: hipLaunchKernelGGL((k_ctpt<LOGN, A, F>), grid, block, 0, s, a); break;
         PF_CASE(0) PF_CASE(1) PF_CASE(2) PF_CASE(3) PF_CASE(4) PF_CASE(5) PF_CASE(6) PF_CASE(7)

@@ -245,4 +245,40 @@ namespace pf {
 #define PF_DECL_LAUNCH(LN) void launch_logn_##LN(int arith, int op, int flags, const NttArgs &a, unsigned grid, hipStream_t s);
 PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_DECL_LAUNCH(14) PF_DECL_LAUNCH(15)
 #undef PF_DECL_LAUNCH
+// pf_ct_rows_mul: out[b] = ct[b / fanout] x pack(ids[b]) with the plaintext packed, transformed and multiplied inside one
+// workgroup per (product, limb); ct in NTT form, out in coefficient form.  Block order: XCD x (blocks x, x + 8, ...) walks
+// the (ciphertext, limb) groups g = x (mod 8) and runs a group's `fanout` products back to back, so the ciphertext limb
+// they share comes from HBM once and from that XCD's L2 after.
+// The 64 registers of the kept plaintext put the kernel at two workgroups per CU whatever it does, so up to N = 8192 it takes
+// the 80 KiB of LDS that leaves it and exchanges through a whole-polynomial buffer (one round and two barriers per exchange
+// instead of two and four; twiddles requested ahead of the exchange).
+template <class A> struct WholeXchg : A { static constexpr bool HALF_EXCHANGE_OK = false; };
+template <class A> struct ArithOf<WholeXchg<A>> {
+    static __device__ __forceinline__ WholeXchg<A> make(const LimbDev &l) { return WholeXchg<A>{ArithOf<A>::make(l)}; }
+    static __device__ __forceinline__ auto fwd(const void *t, const LimbDev &l) { return ArithOf<A>::fwd(t, l); }
+    static __device__ __forceinline__ auto inv(const void *t, const LimbDev &l) { return ArithOf<A>::inv(t, l); }
+};
+template <int LOGN, class A> struct RowsCtptArith { using type = A; };
+template <class A> struct RowsCtptArith<13, A> { using type = WholeXchg<A>; };
+template <class A> struct RowsCtptArith<12, A> { using type = WholeXchg<A>; };
+
+template <int LOGN, class A0>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_rows_ctpt(NttArgs p) {
+    using G = Geo<LOGN>;
+    using A = typename RowsCtptArith<LOGN, A0>::type;
+    __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3, fan = p.ct_fanout;
+    const size_t g = (size_t)(j / fan) * 8 + xcd;             // (input ciphertext, limb)
+    const size_t ctidx = g / p.L, prod = ctidx * fan + j % fan;
+    if (prod >= p.n_pairs) return;                            // n_pairs: number of products here
+    const uint32_t limb = (uint32_t)(g % p.L);
+    const LimbDev &lm = p.limbs[limb];
+    const A ar = ArithOf<A>::make(lm);
+    const RowsLoader<G, A> load{p.rows_xb, p.rows_ids + prod * p.rows_per_poly, p.rows_nb, p.rows_d, p.rows_per_poly, lm.q};
+    const uint64_t *ct = p.src + (ctidx * 2 * p.L + limb) * G::N;
+    uint64_t *out = p.dst + (prod * 2 * p.L + limb) * G::N;
+    body_rows_ctpt<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), ArithOf<A>::inv(p.tables, lm), load, ct, ct + (size_t)p.L * G::N, out,
+                         out + (size_t)p.L * G::N, lds, (int)threadIdx.x, WgSync{});
+}
+
 }  // namespace pf

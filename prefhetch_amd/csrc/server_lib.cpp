@@ -132,7 +132,7 @@ struct Server::Impl {
     size_t nb = 0, nlist = 0;
     // the reference's handlers run on one Drogon loop thread; this lock makes concurrent const calls safe anyway
     mutable std::mutex lock;
-    mutable DevBuf d_query, d_ids, d_out, d_out2, d_pt;
+    mutable DevBuf d_query, d_ids, d_out, d_out2;
     mutable std::unique_ptr<PirState> pir;
     PirState &pir_state() const;
 
@@ -146,7 +146,7 @@ struct Server::Impl {
         if (ring) pf_ctx_destroy(ring);
         pir.reset();
         base = nullptr; centroids = nullptr; ivfpq = nullptr; ring = nullptr;
-        d_query.release(); d_ids.release(); d_out.release(); d_out2.release(); d_pt.release();   // they belong to the old device
+        d_query.release(); d_ids.release(); d_out.release(); d_out2.release();   // they belong to the old device
     }
     // installs trained tables and creates the device objects
     void install(int dev, const float *base_rows, size_t n_base, std::vector<float> cent, std::vector<float> books) {
@@ -356,8 +356,8 @@ void Server::preciseSearch(const std::array<std::array<float, PRECISE_VECTOR_DIM
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }
 
-// The encrypted form of preciseSearch.  Candidate rows are packed 64 to a plaintext polynomial (pf_pack_rows), brought
-// to NTT form and multiplied into the query ciphertext: ENC_POLYS_PER_QUERY = ceil(COARSE_PROBE * 128 / N) = 4
+// The encrypted form of preciseSearch.  Candidate rows are packed 64 to a plaintext polynomial (as pf_pack_rows does), brought
+// to NTT form and multiplied into the query ciphertext (pf_ct_rows_mul: all of it in registers): ENC_POLYS_PER_QUERY = ceil(COARSE_PROBE * 128 / N) = 4
 // ciphertext x plaintext products per query, one fused launch for all of them.
 void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::array<std::array<faiss::idx_t, COARSE_PROBE>, NQUERY> &ids,
                                     uint64_t *result_ct_device) const {
@@ -370,17 +370,15 @@ void Server::preciseSearchEncrypted(const uint64_t *query_ct_device, const std::
     for (size_t q = 0; q < static_cast<size_t>(NQUERY); ++q)
         for (size_t j = 0; j < static_cast<size_t>(COARSE_PROBE); ++j) padded[q * ENC_POLYS_PER_QUERY * ENC_ROWS_PER_POLY + j] = ids[q][j];
     im.d_ids.reserve(im.device, padded.size() * 8);
-    im.d_pt.reserve(im.device, polys * ENC_LIMBS * ENC_RING_DEGREE * 8);
-    uint64_t *pt = static_cast<uint64_t *>(im.d_pt.ptr);
     check(pf_memcpy_h2d(im.device, im.d_ids.ptr, padded.data(), padded.size() * 8, nullptr), "h2d");
-    // plaintexts: packed from the candidate rows inside the forward transform
-    check(pf_pack_rows_ntt(im.ring, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, pt, nullptr), "pf_pack_rows_ntt");
     // the query ciphertexts are transformed once (into a scratch buffer), not once per plaintext block
     constexpr size_t ct_words = static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS * ENC_RING_DEGREE;
     im.d_query.reserve(im.device, ct_words * 8);
     uint64_t *qn = static_cast<uint64_t *>(im.d_query.ptr);
     check(pf_ntt_forward_to(im.ring, query_ct_device, qn, static_cast<size_t>(NQUERY) * 2 * ENC_LIMBS, nullptr), "pf_ntt_forward_to");
-    check(pf_ct_pt_mul_fanout(im.ring, qn, pt, result_ct_device, polys, ENC_POLYS_PER_QUERY, PF_CTPT_IN_NTT, nullptr), "pf_ct_pt_mul_fanout");
+    // plaintexts: packed from the candidate rows, transformed and multiplied into both ciphertext components in one kernel
+    check(pf_ct_rows_mul(im.ring, qn, im.base, static_cast<const int64_t *>(im.d_ids.ptr), polys, ENC_ROWS_PER_POLY, ENC_POLYS_PER_QUERY,
+                         result_ct_device, nullptr), "pf_ct_rows_mul");
     check(pf_stream_synchronize(im.device, nullptr), "sync");
 }
 

@@ -258,6 +258,42 @@ def test_pack_rows_ntt_equals_pack_then_transform(N, qs, rows, force, d):
     assert (fused == oracle.Oracle(N, qs).ntt_forward(oracle.pack_rows(base, ids, N, qs))).all()
 
 
+@pytest.mark.parametrize("N,qs,rows,force,d,B,fan", [(8192, oracle.BFV_DEFAULT[8192][:4], 64, 0, 128, 12, 4), (8192, oracle.BFV_DEFAULT[8192][:4], 64, 2, 128, 7, 3),
+                                                     (8192, oracle.BFV_DEFAULT[8192][:4], 64, 1, 128, 5, 1), (1024, oracle.BFV_DEFAULT[1024], 8, 0, 128, 9, 2),
+                                                     (4096, oracle.BFV_DEFAULT[4096][:2], 40, 1, 100, 10, 4), (16384, [0x7FFFFFD8001, 0x7FFFFFC8001], 128, 0, 128, 5, 2),
+                                                     (16384, [0x7FFFFFFFE90001, 0x7FFFFFD8001], 128, 0, 128, 3, 2),
+                                                     (8192, oracle.BFV_DEFAULT[8192][:4], 81, 0, 100, 6, 6)])
+def test_ct_rows_mul_equals_pack_transform_multiply(N, qs, rows, force, d, B, fan):
+    """pf_ct_rows_mul (rows -> plaintext -> NTT -> x both ciphertext components -> inverse NTT in one workgroup) against
+    pack_rows_ntt + ct_pt_mul_fanout(IN_NTT) and against the oracle, bit for bit, on every arithmetic back-end; B not a
+    multiple of the fan-out, ids out of range, a negated row."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(N + 31 * B + fan)
+    nb = 3000
+    base = rng.integers(0, 256, (nb, d)).astype(np.float32)
+    base[5] = -base[5]
+    ids = rng.integers(0, nb, (B, rows)).astype(np.int64)
+    ids[0, 0], ids[1, rows - 1], ids[2, 0] = 5, -1, nb + 3
+    flat = pf.FlatL2(base, dev)
+    ctx = pf.RnsContext(N, qs, dev)
+    if force:
+        ctx.force_u64(force)
+    L, n_ct = len(qs), -(-B // fan)
+    ct = np.stack([rng.integers(0, q, (n_ct, 2, N), dtype=np.uint64) for q in qs], axis=2)           # [n_ct,2,L,N]
+    d_ids, d_ct = torch.from_numpy(ids).to(dev), pf.to_device_u64(ct, dev)
+    ctn = ctx.ntt_forward(d_ct)
+    one = pf.to_host_u64(ctx.ct_rows_mul(ctn, flat, d_ids, fan))
+    two = pf.to_host_u64(ctx.ct_pt_mul_fanout(ctn, ctx.pack_rows(flat, d_ids, ntt=True), fan, flags=2))
+    assert one.shape == (B, 2, L, N) and (one == two).all()
+    o = oracle.Oracle(N, qs)
+    pt_ntt = o.ntt_forward(oracle.pack_rows(base, ids, N, qs))
+    exp = o.ct_pt_mul(np.ascontiguousarray(ct[np.arange(B) // fan]), pt_ntt)
+    assert (one == exp.reshape(one.shape)).all()
+    with pytest.raises(pf.PfError):
+        ctx.ct_rows_mul(ctn, flat, torch.zeros((B, N // d + 1), dtype=torch.int64, device=dev), fan)
+
+
 def test_step_captured_in_a_hip_graph(pf, capsys):
     """include/prefhetch_hip.h promises that the polynomial calls and pf_flat_search (after pf_flat_reserve) neither
     allocate nor synchronise: the whole step is captured into a hipGraph, replayed on fresh inputs and compared with the
