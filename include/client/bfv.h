@@ -173,6 +173,9 @@ class BatchEncoder {
 // out = Enc(m(X^g)) from in = Enc(m(X)): apply X -> X^g to both components (pf_apply_galois), then switch the second
 // one from s(X^g) back to s (pf_key_switch).  SEAL: Evaluator::apply_galois.
 void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &galois_key, Ciphertexts &out);
+// The same on device pointers, for callers that keep their own buffers: in, out [count][2][L][N] (distinct), scratch
+// [count][L][N] words.  Asynchronous (default stream), no allocation.
+void apply_galois_device(const Context &ctx, const uint64_t *in, size_t count, const SwitchKey &galois_key, uint64_t *out, uint64_t *scratch);
 // the plaintext side of the same map: m(X) -> m(X^g) mod (X^N + 1, t)
 void apply_galois_plain(const uint64_t *plain, uint32_t N, uint64_t t, uint32_t galois_elt, uint64_t *out);
 

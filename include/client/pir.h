@@ -14,7 +14,8 @@
 //              form: the "plaintext" operand of pf_ct_pt_mul.  n_polys <= 2^levels <= N.
 //   query      Enc(2^-levels * X^p) for the polynomial p that holds the wanted row (one ciphertext).
 //   expand     levels rounds; round j maps every ciphertext c to (c + s_j(c), (c - s_j(c)) * X^(-2^j)) with the Galois
-//              automorphism s_j: X -> X^(N / 2^j + 1) (pf_apply_galois + pf_key_switch): 2^levels ciphertexts, the k-th
+//              automorphism s_j: X -> X^(N / 2^j + 1) (pf_apply_galois_ct + pf_key_switch) and the monomial product a signed
+//              coefficient shift (pf_poly_mul_monomial): 2^levels ciphertexts, the k-th
 //              encrypting 1 if k = p and 0 otherwise.
 //   answer     sum_k expanded_k x database_k = Enc(database_p): pf_ct_pt_mul with NTT-form output, a tree of pf_poly_add,
 //              one inverse transform.
@@ -49,9 +50,14 @@ class Database {
     Database(const bfv::Context &ctx, const float *rows, size_t n_rows, uint32_t d);
     const Layout &layout() const { return m_Layout; }
     const uint64_t *ntt() const { return m_Ntt.ptr(); }       // [n_polys][L][N], NTT form
+    // Buffers of expand / answer, kept between calls (a retrieval at 262 144 rows works in 13 GB: allocating them per call cost
+    // more than the arithmetic).  Not thread-safe: one answer() at a time per Database.
+    struct Workspace { bfv::Ciphertexts sel, one; bfv::DeviceWords rot, scratch, prod; };
+    Workspace &workspace() const { return m_Ws; }
   private:
     Layout m_Layout;
     bfv::DeviceWords m_Ntt;
+    mutable Workspace m_Ws;
 };
 
 // The Galois elements the expansion needs, round 0 first: N / 2^j + 1.
@@ -63,7 +69,7 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
             bfv::Ciphertexts &reply);
 // the expansion alone (test hook): one query ciphertext -> 2^levels selection ciphertexts
 void expand(const bfv::Context &ctx, const bfv::Ciphertexts &query_one, const std::vector<bfv::SwitchKey> &keys, uint32_t levels,
-            bfv::Ciphertexts &out);
+            bfv::Ciphertexts &out, Database::Workspace *ws = nullptr);
 
 // ---- client side ------------------------------------------------------------------------------------------------
 // plaintext of the query for `row`: 2^-levels mod t at coefficient poly_of(row)

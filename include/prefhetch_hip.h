@@ -106,8 +106,21 @@ pf_status pf_ct_pt_mul(pf_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, 
  * rotate_rows / rotate_columns: out(X) = in(X^galois_elt) mod (X^N + 1), i.e. coefficient i moves to position
  * i * galois_elt mod 2N, negated when that position is >= N.  galois_elt odd, in [1, 2N).  out must not alias in.
  * Follow with pf_key_switch (target = the permuted c1, key = the Galois key of galois_elt) to return to the original
- * secret key.  HBM-bound, 16 bytes per coefficient. */
+ * secret key.  HBM-bound, 16 bytes per coefficient (contiguous writes, permuted reads). */
 pf_status pf_apply_galois(pf_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n_limb_polys, uint32_t galois_elt, pf_stream stream);
+/* util::negacyclic_shift_poly_coeffmod: out = in * X^exponent mod (X^N + 1) on coefficient-form limb-polynomials,
+ * exponent in [0, 2N) (X^-s = X^(2N - s)); coefficient i moves to i + exponent mod 2N, negated when that is >= N.
+ * out must not alias in.  HBM-bound, 16 bytes per coefficient. */
+pf_status pf_poly_mul_monomial(pf_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n_limb_polys, uint32_t exponent, pf_stream stream);
+/* sum = a + b and diff = (a - b) * X^exponent in one pass (the butterfly of SealPIR's query expansion: add_inplace,
+ * sub_inplace and multiply_power_of_X).  sum may alias a or b; diff must alias nothing.  32 bytes per coefficient. */
+pf_status pf_poly_addsub_monomial(pf_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *sum, uint64_t *diff, size_t n_limb_polys,
+                                  uint32_t exponent, pf_stream stream);
+/* The same permutation over B ciphertexts [B][2][L][N] in ONE launch, laid out for the key switch that follows
+ * (the prologue of Evaluator::apply_galois_inplace): ct_out[b][0] = tau(ct_in[b][0]), ct_out[b][1] = 0,
+ * target[b] = tau(ct_in[b][1]) ([B][L][N]); then pf_key_switch(key ring, target, galois key, ct_out, B). */
+pf_status pf_apply_galois_ct(pf_ctx *ctx, const uint64_t *ct_in, uint64_t *ct_out, uint64_t *target, size_t B, uint32_t galois_elt,
+                             pf_stream stream);
 
 /* Evaluator::switch_key_inplace (what relinearize_inplace / rotate_rows / apply_galois run), BFV form: the
  * polynomial `target` (coefficient form) is re-encrypted under the secret key through the key-switching key and
@@ -117,7 +130,7 @@ pf_status pf_apply_galois(pf_ctx *ctx, const uint64_t *in, uint64_t *out, size_t
  *   ksk    [D][2][D+1][N]   digit I's key as SEAL stores it (PublicKey data: 2 polys x K limbs), NTT form
  *   ct     [B][2][D][N]     coefficient form, updated in place
  * RNS digit decomposition -> D*(D+1) forward NTTs -> 128-bit lazy multiply-accumulate with the key ->
- * inverse NTTs -> division by P with rounding.  Uses an internal workspace (16 ciphertexts per round) that is
+ * inverse NTTs -> division by P with rounding.  Uses an internal workspace (~4096 digit transforms per round: 16 ciphertexts at config 5, 205 at N = 8192) that is
  * allocated on first use: call once outside graph capture. */
 pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
 

@@ -165,6 +165,38 @@ class RnsContext:
         check(lib.pf_apply_galois(self._h, pi, po, polys.numel() // self.N, int(galois_elt), _stream(self.device)), "pf_apply_galois")
         return out
 
+    def mul_monomial(self, polys, exponent, out=None):
+        """out = polys * X^exponent mod (X^N + 1), exponent in [0, 2N), coefficient-form limb-polynomials [..., L, N]."""
+        if polys.numel() % (self.L * self.N):
+            raise ValueError("size is not a multiple of L*N")
+        if out is None:
+            out = torch.empty_like(polys)
+        pi, po = _req(polys, torch.int64, self.device_index, "polys"), _req(out, torch.int64, self.device_index, "out")
+        check(lib.pf_poly_mul_monomial(self._h, pi, po, polys.numel() // self.N, int(exponent), _stream(self.device)), "pf_poly_mul_monomial")
+        return out
+
+    def addsub_monomial(self, a, b, exponent, sum_out=None, diff_out=None):
+        """(a + b, (a - b) * X^exponent) in one pass; coefficient-form limb-polynomials [..., L, N]."""
+        if a.numel() % (self.L * self.N) or a.numel() != b.numel():
+            raise ValueError("sizes must agree and be a multiple of L*N")
+        sum_out = torch.empty_like(a) if sum_out is None else sum_out
+        diff_out = torch.empty_like(a) if diff_out is None else diff_out
+        pa, pb, ps, pd = (_req(t, torch.int64, self.device_index, n) for t, n in ((a, "a"), (b, "b"), (sum_out, "sum"), (diff_out, "diff")))
+        check(lib.pf_poly_addsub_monomial(self._h, pa, pb, ps, pd, a.numel() // self.N, int(exponent), _stream(self.device)), "pf_poly_addsub_monomial")
+        return sum_out, diff_out
+
+    def apply_galois_ct(self, ct, galois_elt):
+        """The permutation over ciphertexts [B,2,L,N], laid out for the key switch that follows: returns (ct_out, target) with
+        ct_out[b,0] = tau(ct[b,0]), ct_out[b,1] = 0, target[b] = tau(ct[b,1]) ([B,L,N])."""
+        if ct.numel() % (2 * self.L * self.N):
+            raise ValueError("size is not a multiple of 2*L*N")
+        B = ct.numel() // (2 * self.L * self.N)
+        out = torch.empty_like(ct)
+        target = torch.empty((B, self.L, self.N), dtype=torch.int64, device=self.device)
+        pi, po, pt = (_req(t, torch.int64, self.device_index, n) for t, n in ((ct, "ct"), (out, "out"), (target, "target")))
+        check(lib.pf_apply_galois_ct(self._h, pi, po, pt, B, int(galois_elt), _stream(self.device)), "pf_apply_galois_ct")
+        return out, target
+
     def pack_rows(self, flat, ids, out=None, ntt=False):
         """Plaintext polynomials of the encrypted precise search: ids [n_polys, rows_per_poly] (int64, device) rows of
         the FlatL2 index `flat` -> [n_polys, L, N] coefficient-form residues (follow with ntt_forward_), or, with

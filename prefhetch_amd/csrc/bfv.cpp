@@ -577,23 +577,23 @@ void BatchEncoder::decode(const uint64_t *plain, uint64_t *values_out) const {
 }
 
 // ---- Galois automorphism on ciphertexts ----------------------------------------------------------------------
-void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &key, Ciphertexts &out) {
+void apply_galois_device(const Context &ctx, const uint64_t *in, size_t count, const SwitchKey &key, uint64_t *out, uint64_t *scratch) {
     if (!ctx.key_ring()) throw std::runtime_error("bfv: these parameters have no special prime: key switching is not available");
     if (!key.galois_elt) throw std::invalid_argument("bfv::apply_galois: not a Galois key");
+    if (count == 0) return;
+    // tau(c0) into the first component, zeros into the second, tau(c1) = the polynomial to switch: one launch for the batch
+    check(pf_apply_galois_ct(ctx.ring(), in, out, scratch, count, key.galois_elt, nullptr), "pf_apply_galois_ct");
+    check(pf_key_switch(ctx.key_ring(), scratch, key.ksk.ptr(), out, count, nullptr), "pf_key_switch");
+}
+
+void apply_galois(const Context &ctx, const Ciphertexts &in, const SwitchKey &key, Ciphertexts &out) {
     const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N;
     const int dev = ctx.params().device;
     out.count = in.count;
     if (in.count == 0) return;
     if (out.data.words() < in.count * per) out.data = DeviceWords(dev, in.count * per);
     DeviceWords target(dev, in.count * L * N);
-    for (size_t i = 0; i < in.count; ++i) {
-        const uint64_t *c0 = in.data.ptr() + i * per, *c1 = c0 + L * N;
-        uint64_t *o0 = out.data.ptr() + i * per, *o1 = o0 + L * N, *tg = target.ptr() + i * L * N;
-        check(pf_apply_galois(ctx.ring(), c0, o0, L, key.galois_elt, nullptr), "pf_apply_galois");       // tau(c0)
-        check(pf_apply_galois(ctx.ring(), c1, tg, L, key.galois_elt, nullptr), "pf_apply_galois");       // tau(c1): the polynomial to switch
-        check(pf_poly_sub(ctx.ring(), tg, tg, o1, L, nullptr), "pf_poly_sub");                            // second component starts at zero
-    }
-    check(pf_key_switch(ctx.key_ring(), target.ptr(), key.ksk.ptr(), out.data.ptr(), in.count, nullptr), "pf_key_switch");
+    apply_galois_device(ctx, in.data.ptr(), in.count, key, out.data.ptr(), target.ptr());
     check(pf_stream_synchronize(dev, nullptr), "sync");
 }
 

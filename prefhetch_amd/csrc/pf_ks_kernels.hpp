@@ -134,22 +134,73 @@ __global__ void __launch_bounds__(256) k_pack_rows(PackArgs p) {
 }
 
 // ---- Galois automorphism X -> X^g on coefficient-form polynomials (pf_apply_galois) ---------------------------
-// One thread per INPUT coefficient: reads are coalesced, writes follow the permutation (stride g: lanes hit distinct
-// 8-byte words of a few cache lines).  16 B of traffic per coefficient.
+// One thread per OUTPUT coefficient c: the source is i = c * g^-1 mod 2N (g^-1 mod 2N from the host), taken negated when
+// i >= N (then (i - N) * g = c + N mod 2N).  Writes are contiguous, reads follow the permutation: the round-2 form (thread per
+// input, scattered 8-byte writes) ran at 1.7 TB/s on the private retrieval's batches -- strided stores cost several times what
+// strided loads do here (tools/ubench_stride.hip).  16 B of traffic per coefficient.
 struct GaloisArgs {
     const LimbDev *limbs;
     const uint64_t *in; uint64_t *out;
-    uint32_t L, logn, galois_elt;
+    uint32_t L, logn, galois_inv;
+    uint64_t *target;            // ciphertext form (pf_apply_galois_ct): the permuted second components go here, zeros to `out`
 };
 
 __global__ void __launch_bounds__(256) k_apply_galois(GaloisArgs p) {
     const uint32_t N = 1u << p.logn, per = N / 256;
     const size_t poly = blockIdx.x / per;
-    const uint32_t i = (uint32_t)(blockIdx.x % per) * 256 + threadIdx.x;
+    const uint32_t c = (uint32_t)(blockIdx.x % per) * 256 + threadIdx.x;
+    const uint32_t l = (uint32_t)(poly % p.L);
+    const uint64_t q = p.limbs[l].q;
+    const uint32_t i = (uint32_t)(((uint64_t)c * p.galois_inv) & (2u * N - 1));
+    const uint64_t v = p.in[poly * N + (i & (N - 1))];
+    uint64_t *dst = p.out + poly * N;
+    if (p.target) {                                            // poly = (b * 2 + component) * L + l
+        const size_t bc = poly / p.L;
+        if (bc & 1) {
+            dst[c] = 0;
+            dst = p.target + ((bc >> 1) * p.L + l) * N;
+        }
+    }
+    dst[c] = (i >= N && v) ? q - v : v;
+}
+
+// ---- sum and shifted difference in one pass (pf_poly_addsub_monomial): sum = a + b, diff = (a - b) * X^k ------------------
+// The butterfly of SealPIR's query expansion.  One thread per coefficient; sum may alias a or b.  32 B of traffic per coefficient.
+struct AddSubArgs {
+    const LimbDev *limbs;
+    const uint64_t *a, *b; uint64_t *sum, *diff;
+    uint32_t L, logn, shift;
+};
+
+__global__ void __launch_bounds__(256) k_addsub_monomial(AddSubArgs p) {
+    const uint32_t N = 1u << p.logn, per = N / 256;
+    const size_t poly = blockIdx.x / per;
+    const uint32_t c = (uint32_t)(blockIdx.x % per) * 256 + threadIdx.x;
     const uint64_t q = p.limbs[poly % p.L].q;
-    const uint64_t v = p.in[poly * N + i];
-    const uint32_t j = (uint32_t)(((uint64_t)i * p.galois_elt) & (2u * N - 1));
-    p.out[poly * N + (j & (N - 1))] = (j >= N && v) ? q - v : v;
+    const uint64_t x = p.a[poly * N + c], y = p.b[poly * N + c];
+    const uint64_t s = x + y, d = x >= y ? x - y : x + q - y;
+    p.sum[poly * N + c] = s >= q ? s - q : s;
+    const uint32_t j = (c + p.shift) & (2u * N - 1);
+    p.diff[poly * N + (j & (N - 1))] = (j >= N && d) ? q - d : d;
+}
+
+// ---- product with a monomial X^k, k in [0, 2N) (pf_poly_mul_monomial; SEAL util::negacyclic_shift_poly_coeffmod) ----------
+// One thread per OUTPUT coefficient: out[c] = in[c - k] for c >= k (mod 2N bookkeeping: an index that wraps past N once picks
+// up a minus sign).  Reads and writes are both contiguous.  16 B of traffic per coefficient.
+struct MonoArgs {
+    const LimbDev *limbs;
+    const uint64_t *in; uint64_t *out;
+    uint32_t L, logn, shift;
+};
+
+__global__ void __launch_bounds__(256) k_mul_monomial(MonoArgs p) {
+    const uint32_t N = 1u << p.logn, per = N / 256;
+    const size_t poly = blockIdx.x / per;
+    const uint32_t c = (uint32_t)(blockIdx.x % per) * 256 + threadIdx.x;
+    const uint64_t q = p.limbs[poly % p.L].q;
+    const uint32_t i = (c - p.shift) & (2u * N - 1);           // source index in [0, 2N): X^i * X^k = X^c up to the sign of X^N = -1
+    const uint64_t v = p.in[poly * N + (i & (N - 1))];
+    p.out[poly * N + c] = (i >= N && v) ? q - v : v;
 }
 
 }  // namespace pf

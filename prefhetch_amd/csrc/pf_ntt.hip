@@ -51,6 +51,13 @@ pf_status dispatch_logn(const pf_ctx *c, int arith, int op, int flags, const Ntt
     return PF_OK;
 }
 
+// inverse of an odd g modulo 2N (a power of two): Newton's iteration doubles the correct low bits each step
+uint32_t inverse_mod_2n(uint32_t g, uint32_t N) {
+    uint32_t inv = g;                                         // correct to 3 bits for odd g
+    for (int it = 0; it < 5; ++it) inv *= 2u - g * inv;
+    return inv & (2u * N - 1);
+}
+
 pf_status run_ntt_like(pf_ctx *c, int op, int flags, const NttArgs &a, size_t n, pf_stream stream) {
     if (n == 0) return PF_OK;
     if (n > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
@@ -336,7 +343,53 @@ pf_status pf_apply_galois(pf_ctx *c, const uint64_t *in, uint64_t *out, size_t n
     const size_t blocks = n * (c->N / 256);
     if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
     PF_GUARD(c->device);
-    GaloisArgs a{c->d_limbs, in, out, c->L, c->logn, galois_elt};
+    GaloisArgs a{c->d_limbs, in, out, c->L, c->logn, inverse_mod_2n(galois_elt, c->N), nullptr};
+    hipLaunchKernelGGL(k_apply_galois, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status pf_poly_mul_monomial(pf_ctx *c, const uint64_t *in, uint64_t *out, size_t n, uint32_t exponent, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (n == 0) return PF_OK;
+    if (!in || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (in == out) return fail(PF_ERR_INVALID_ARG, "pf_poly_mul_monomial is not an in-place operation");
+    if (exponent >= 2 * c->N) return fail(PF_ERR_INVALID_ARG, "exponent must be below 2N");
+    const size_t blocks = n * (c->N / 256);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
+    PF_GUARD(c->device);
+    MonoArgs a{c->d_limbs, in, out, c->L, c->logn, exponent};
+    hipLaunchKernelGGL(k_mul_monomial, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status pf_poly_addsub_monomial(pf_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *sum, uint64_t *diff, size_t n, uint32_t exponent,
+                                  pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (n == 0) return PF_OK;
+    if (!a || !b || !sum || !diff) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (diff == a || diff == b || diff == sum) return fail(PF_ERR_INVALID_ARG, "pf_poly_addsub_monomial: diff must not alias the other operands");
+    if (exponent >= 2 * c->N) return fail(PF_ERR_INVALID_ARG, "exponent must be below 2N");
+    const size_t blocks = n * (c->N / 256);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
+    PF_GUARD(c->device);
+    AddSubArgs k{c->d_limbs, a, b, sum, diff, c->L, c->logn, exponent};
+    hipLaunchKernelGGL(k_addsub_monomial, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+pf_status pf_apply_galois_ct(pf_ctx *c, const uint64_t *ct_in, uint64_t *ct_out, uint64_t *target, size_t B, uint32_t galois_elt, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (B == 0) return PF_OK;
+    if (!ct_in || !ct_out || !target) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (ct_in == ct_out || ct_in == target) return fail(PF_ERR_INVALID_ARG, "pf_apply_galois_ct is not an in-place operation");
+    if (!(galois_elt & 1) || galois_elt >= 2 * c->N) return fail(PF_ERR_INVALID_ARG, "galois_elt must be odd and below 2N");
+    const size_t blocks = B * 2 * c->L * (c->N / 256);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many limb-polynomials for one launch");
+    PF_GUARD(c->device);
+    GaloisArgs a{c->d_limbs, ct_in, ct_out, c->L, c->logn, inverse_mod_2n(galois_elt, c->N), target};
     hipLaunchKernelGGL(k_apply_galois, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     PF_HIP(hipGetLastError());
     return PF_OK;
@@ -352,7 +405,11 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     PF_GUARD(c->device);
     hipStream_t s = as_stream(stream);
     const size_t N = c->N;
-    const size_t sub = B < 16 ? B : 16;                                   // ciphertexts per round of the workspace
+    // ciphertexts per round of the workspace: enough for ~4096 digit transforms per launch (16 at config 5's 15 x 16 digit
+    // transforms per ciphertext = 1.1 GB of workspace; 205 at N = 8192 with 4 + 1 moduli = 0.4 GB)
+    size_t sub = (4096 + (size_t)D * K - 1) / ((size_t)D * K);
+    if (sub < 16) sub = 16;
+    if (sub > B) sub = B;
     const size_t x_words = sub * D * K * N, acc_words = sub * 2 * K * N;
     const size_t need = (x_words + acc_words) * 8;
     if (need > c->ks_ws_bytes) {

@@ -1,8 +1,11 @@
 // pir.cpp -- see include/client/pir.h.  Host C++ over the C ABI (prefhetch_hip.h) and the BFV helpers (bfv.h): every
-// ring operation runs on the GPU -- pf_ct_pt_mul (monomial products of the expansion, the database products),
-// pf_apply_galois + pf_key_switch (bfv::apply_galois), pf_poly_add / pf_poly_sub, pf_ntt_forward / pf_ntt_inverse.
+// ring operation runs on the GPU -- pf_ct_pt_mul (the database products), pf_apply_galois_ct + pf_key_switch
+// (bfv::apply_galois), pf_poly_add / pf_poly_sub / pf_poly_mul_monomial (the expansion's butterflies), pf_ntt_forward / pf_ntt_inverse.
 #include "../../include/client/pir.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -73,7 +76,7 @@ std::vector<uint32_t> galois_elements(uint32_t N, uint32_t levels) {
 }
 
 void expand(const bfv::Context &ctx, const bfv::Ciphertexts &query_one, const std::vector<bfv::SwitchKey> &keys, uint32_t levels,
-            bfv::Ciphertexts &out) {
+            bfv::Ciphertexts &out, Database::Workspace *ws) {
     if (query_one.count != 1) throw std::invalid_argument("pir::expand: one query ciphertext at a time");
     if (keys.size() < levels) throw std::invalid_argument("pir::expand: a Galois key per round is needed");
     const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, n_out = size_t{1} << levels;
@@ -82,28 +85,19 @@ void expand(const bfv::Context &ctx, const bfv::Ciphertexts &query_one, const st
     out.count = n_out;
     if (out.data.words() < n_out * per) out.data = bfv::DeviceWords(dev, n_out * per);
     check(pf_memcpy_d2d(dev, out.data.ptr(), query_one.data.ptr(), per * 8, nullptr), "d2d");
-    // the monomials X^(-2^j) = -X^(N - 2^j) of all rounds, as NTT-form "plaintexts" of pf_ct_pt_mul
-    std::vector<uint64_t> mono(levels * L * N, 0);
-    for (uint32_t j = 0; j < levels; ++j)
-        for (size_t l = 0; l < L; ++l) mono[(j * L + l) * N + (N - (size_t{1} << j))] = ctx.params().moduli[l] - 1;
-    bfv::DeviceWords d_mono(dev, mono.size() ? mono.size() : 1);
-    if (levels) {
-        d_mono.upload(mono.data(), mono.size());
-        check(pf_ntt_forward(ctx.ring(), d_mono.ptr(), (size_t)levels * L, nullptr), "pf_ntt_forward");
-    }
-    bfv::Ciphertexts cur, rot;
+    // s_j(c) of a round and the polynomials its key switch works on, sized for the last (largest) round
+    Database::Workspace local;
+    Database::Workspace &w = ws ? *ws : local;
+    if (levels && w.rot.words() < (n_out / 2) * per) w.rot = bfv::DeviceWords(dev, (n_out / 2) * per);
+    if (levels && w.scratch.words() < (n_out / 2) * L * N) w.scratch = bfv::DeviceWords(dev, (n_out / 2) * L * N);
     for (uint32_t j = 0; j < levels; ++j) {
         if (keys[j].galois_elt != elts[j]) throw std::invalid_argument("pir::expand: keys[j] must be the Galois key of N / 2^j + 1");
         const size_t B = size_t{1} << j;
-        // the first B ciphertexts of `out` are this round's inputs
-        cur.count = B;
-        if (cur.data.words() < B * per) cur.data = bfv::DeviceWords(dev, B * per);
-        check(pf_memcpy_d2d(dev, cur.data.ptr(), out.data.ptr(), B * per * 8, nullptr), "d2d");
-        bfv::apply_galois(ctx, cur, keys[j], rot);                                       // s_j(c): automorphism + key switch, B at once
+        // the first B ciphertexts of `out` are this round's inputs c; they become c + s_j(c) in place, the next B are (c - s_j(c)) * X^(-2^j)
         uint64_t *lo = out.data.ptr(), *hi = out.data.ptr() + B * per;
-        check(pf_poly_sub(ctx.ring(), cur.data.ptr(), rot.data.ptr(), hi, B * 2 * L, nullptr), "pf_poly_sub");          // c - s_j(c)
-        check(pf_poly_add(ctx.ring(), cur.data.ptr(), rot.data.ptr(), lo, B * 2 * L, nullptr), "pf_poly_add");          // c + s_j(c)
-        check(pf_ct_pt_mul(ctx.ring(), hi, d_mono.ptr() + (size_t)j * L * N, 1, hi, B, 0, nullptr), "pf_ct_pt_mul");   // * X^(-2^j)
+        bfv::apply_galois_device(ctx, lo, B, keys[j], w.rot.ptr(), w.scratch.ptr());     // automorphism + key switch, B at once
+        // X^(-2^j) = X^(2N - 2^j): a signed shift of the coefficients (SealPIR's multiply_power_of_X), fused with the sum and the difference
+        check(pf_poly_addsub_monomial(ctx.ring(), lo, w.rot.ptr(), lo, hi, B * 2 * L, 2 * ctx.N() - (1u << j), nullptr), "pf_poly_addsub_monomial");
     }
     check(pf_stream_synchronize(dev, nullptr), "sync");
 }
@@ -116,15 +110,28 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
     reply.count = query.count;
     if (query.count == 0) return;
     if (reply.data.words() < query.count * per) reply.data = bfv::DeviceWords(dev, query.count * per);
-    bfv::Ciphertexts one, sel;
+    Database::Workspace &w = db.workspace();
+    bfv::Ciphertexts &one = w.one, &sel = w.sel;
     one.count = 1;
-    one.data = bfv::DeviceWords(dev, per);
-    bfv::DeviceWords prod(dev, P * per);
+    if (one.data.words() < per) one.data = bfv::DeviceWords(dev, per);
+    if (w.prod.words() < P * per) w.prod = bfv::DeviceWords(dev, P * per);
+    bfv::DeviceWords &prod = w.prod;
+    const bool trace = std::getenv("PF_PIR_TRACE") != nullptr;
+    auto stamp = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+        if (!trace) return;
+        pf_stream_synchronize(dev, nullptr);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pir::answer %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     for (size_t q = 0; q < query.count; ++q) {
+        auto t0 = std::chrono::steady_clock::now();
         check(pf_memcpy_d2d(dev, one.data.ptr(), query.data.ptr() + q * per, per * 8, nullptr), "d2d");
-        expand(ctx, one, keys, lay.levels, sel);
+        expand(ctx, one, keys, lay.levels, sel, &w);
+        stamp("expand", t0);
         // products in NTT form, summed there by halving (one launch per halving), one inverse transform at the end
         check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt(), P, prod.ptr(), P, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
+        stamp("products", t0);
         for (size_t n = P; n > 1;) {
             const size_t half = n / 2, keep = n - half;                                  // fold the last `half` onto the first `half`
             check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
@@ -132,6 +139,7 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
         }
         uint64_t *out = reply.data.ptr() + q * per;
         check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), out, 2 * L, nullptr), "pf_ntt_inverse_to");
+        stamp("sum + inv", t0);
     }
     check(pf_stream_synchronize(dev, nullptr), "sync");
 }

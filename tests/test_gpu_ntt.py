@@ -332,6 +332,48 @@ def test_apply_galois(pf, N, qs):
         c.apply_galois(d, 4)
     with pytest.raises(pf.PfError):
         c.apply_galois(d, 3, out=d)
+    # the ciphertext form (one launch for a batch, laid out for pf_key_switch): [2 ciphertexts][2][L][N]
+    for g in (3, 2 * N - 1, N + 1):
+        ct_out, target = (pf.to_host_u64(t) for t in c.apply_galois_ct(d.view(2, 2, L, N), g))
+        exp = oracle.apply_galois(a, g, qs).reshape(2, 2, L, N)
+        assert (ct_out[:, 0] == exp[:, 0]).all() and (ct_out[:, 1] == 0).all() and (target == exp[:, 1]).all(), g
+
+
+@pytest.mark.parametrize("N,qs", [(1024, oracle.BFV_DEFAULT[1024]), (8192, oracle.BFV_DEFAULT[8192][:4])])
+def test_mul_monomial(pf, N, qs):
+    """pf_poly_mul_monomial against the definition (coefficient i -> i + k mod 2N, negated past N) and against the NTT product
+    with the monomial as a polynomial."""
+    rng = np.random.default_rng(N + 1)
+    a = np.stack([np.stack([edge_poly(rng, N, q, kind) for q in qs]) for kind in (0, 1, 3)])       # [3][L][N]
+    c = _ctx(pf, N, qs)
+    d = pf.to_device_u64(a, _dev())
+    o = oracle.Oracle(N, qs)
+    qv = np.array(qs, dtype=np.uint64)[None, :, None]
+    for k in (0, 1, N - 1, N, N + 5, 2 * N - 1, 2 * N - 64):
+        idx = (np.arange(N) + k) % (2 * N)
+        exp = np.zeros_like(a)
+        neg = np.where(a == 0, a, qv - a)
+        exp[..., idx % N] = np.where(idx >= N, neg, a)
+        got = pf.to_host_u64(c.mul_monomial(d, k))
+        assert (got == exp).all(), k
+        mono = np.zeros((len(qs), N), dtype=np.uint64)
+        for l, q in enumerate(qs):
+            mono[l, k % N] = 1 if k < N else q - 1
+        prod = o.ntt_inverse(o.dyadic_mul(o.ntt_forward(a[0]), o.ntt_forward(mono)))
+        assert (got[0] == prod).all(), k
+    # sum and shifted difference in one pass, the sum in place
+    b = pf.to_device_u64(a[::-1].copy(), _dev())
+    for k in (1, 2 * N - 4, N):
+        exp_sum, exp_diff = pf.to_host_u64(c.add(d, b)), pf.to_host_u64(c.mul_monomial(c.sub(d, b), k))
+        a2 = d.clone()
+        s_, d_ = c.addsub_monomial(a2, b, k, sum_out=a2)
+        assert (pf.to_host_u64(s_) == exp_sum).all() and (pf.to_host_u64(d_) == exp_diff).all(), k
+    with pytest.raises(pf.PfError):
+        c.addsub_monomial(d, b, 1, diff_out=d)
+    with pytest.raises(pf.PfError):
+        c.mul_monomial(d, 2 * N)
+    with pytest.raises(pf.PfError):
+        c.mul_monomial(d, 3, out=d)
 
 
 def test_out_of_place_transforms(pf):
