@@ -405,9 +405,9 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     PF_GUARD(c->device);
     hipStream_t s = as_stream(stream);
     const size_t N = c->N;
-    // ciphertexts per round of the workspace: enough for ~4096 digit transforms per launch (16 at config 5's 15 x 16 digit
-    // transforms per ciphertext = 1.1 GB of workspace; 205 at N = 8192 with 4 + 1 moduli = 0.4 GB)
-    size_t sub = (4096 + (size_t)D * K - 1) / ((size_t)D * K);
+    // ciphertexts per round of the workspace: a multiple of 16 with at most ~4096 digit transforms per launch (16 at config 5's
+    // 15 x 16 digit transforms per ciphertext = 1.1 GB of workspace; 192 at N = 8192 with 4 + 1 moduli = 0.4 GB)
+    size_t sub = 4096 / ((size_t)D * K) / 16 * 16;
     if (sub < 16) sub = 16;
     if (sub > B) sub = B;
     const size_t x_words = sub * D * K * N, acc_words = sub * 2 * K * N;

@@ -22,4 +22,8 @@ python3 tools/time_ivfpq.py > $O/${tag}_ivfpq.json 2> $O/${tag}_ivfpq.err
 cd /tmp && PF_CONFIG=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_ks -- python3 $R/tools/run_kernel.py keyswitch 2 256 > $O/${tag}_keyswitch.txt 2>&1
 cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_ks -name "*kernel_stats.csv" | head -1) $O/${tag}_keyswitch_kernel_stats.txt
 tail -3 $O/${tag}_keyswitch.txt
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_enc -- python3 $R/tools/run_kernel.py encround 5 1024 > $O/${tag}_encround.txt 2>&1
+cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_enc -name "*kernel_stats.csv" | head -1) $O/${tag}_encround_kernel_stats.txt
+tail -2 $O/${tag}_encround.txt
+[ -x tools/time_pir ] && timeout -k 10 400 tools/time_pir 262144 2 > $O/${tag}_pir_262144_rows.json 2> $O/${tag}_pir.err
 cat $O/${tag}_bench.json | head -c 600; echo

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs ONE hot-path kernel a few times on synthetic BASELINE config-3 data (for rocprofv3 --pmc / --kernel-trace).
-usage: python3 tools/run_kernel.py {ctpt|ntt_fwd|ntt_inv|dyadic|flat} [reps] [batch]"""
+usage: python3 tools/run_kernel.py {ctpt|ntt_fwd|ntt_inv|dyadic|flat|encround|keyswitch} [reps] [batch]"""
 import os
 import sys
 
@@ -38,6 +38,26 @@ if what == "keyswitch":          # PF_CONFIG=5: N=32768, 15 data primes + specia
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print("keyswitch: %.3f ms per batch of %d (%.1f us per switched polynomial), %d digit NTTs of N=%d" % (ms, B, 1e3 * ms / B, B * D * K, N))
+    sys.exit(0)
+if what == "encround":           # the server side of the encrypted precise search: NTT of the query ciphertexts + pf_ct_rows_mul
+    fan, rows, K = 4, N // 128, 200
+    xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
+    flat = pf.FlatL2(xb, dev)
+    ctx = pf.RnsContext(N, MODULI, dev)
+    ct = torch.stack([torch.randint(0, q, (B, 2, N), generator=g, device=dev, dtype=torch.int64) for q in MODULI], dim=2).contiguous()
+    ids = torch.full((B * fan, rows), -1, dtype=torch.int64, device=dev)
+    ids.view(B, fan * rows)[:, :K] = torch.randint(0, 1_000_000, (B, K), generator=g, device=dev)
+    ctn, res = torch.empty_like(ct), torch.empty((B * fan, 2, len(MODULI), N), dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(reps + 1):
+        if r == 1:
+            e0.record()
+        ctx.ntt_forward(ct, out=ctn)
+        ctx.ct_rows_mul(ctn, flat, ids, fan, out=res)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("encround: %.3f ms per %d queries x %d candidates (%d products): %.0f encrypted precise queries/s" % (ms, B, K, B * fan, B / ms * 1e3))
     sys.exit(0)
 if what == "flat":
     xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
