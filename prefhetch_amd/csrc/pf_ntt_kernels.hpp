@@ -86,13 +86,28 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ks
                            (int)threadIdx.x, WgSync{});
 }
 
+// The same arithmetic, exchanging through a whole-polynomial LDS buffer (one round and two barriers per exchange instead of two
+// and four; twiddles requested ahead of the exchange): for kernels that sit at two workgroups per CU anyway (k_rows_ctpt).
+template <class A> struct WholeXchg : A { static constexpr bool HALF_EXCHANGE_OK = false; };
+template <class A> struct ArithOf<WholeXchg<A>> {
+    static __device__ __forceinline__ WholeXchg<A> make(const LimbDev &l) { return WholeXchg<A>{ArithOf<A>::make(l)}; }
+    static __device__ __forceinline__ auto fwd(const void *t, const LimbDev &l) { return ArithOf<A>::fwd(t, l); }
+    static __device__ __forceinline__ auto inv(const void *t, const LimbDev &l) { return ArithOf<A>::inv(t, l); }
+};
+
 // Fused ct x pt over the ciphertext batch [B][2][L][N].  XCD-aware block order: blocks b and b+8 share an XCD
 // under round-robin placement, so XCD x takes the (ciphertext, limb) pairs m = x (mod 8) and runs the two
 // polynomials of a pair back to back -- the plaintext limb pt[b][l] they both multiply by is fetched from HBM
 // once and re-read from that XCD's L2 (rocprof FETCH_SIZE showed it coming from memory twice under the natural
 // order).  For L | 8 an XCD still only ever touches one or two limbs' twiddle tables.
+#ifdef PF_CTPT_WHOLE     // experiment (N = 8192): two workgroups per CU with the whole-polynomial exchange; measured 0.47 ms against 0.445 sustained
+template <int LOGN, class A0, int FLAGS>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ctpt(NttArgs p) {
+    using A = WholeXchg<A0>;
+#else
 template <int LOGN, class A, int FLAGS>
 __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ctpt(NttArgs p) {
+#endif
     using G = Geo<LOGN>;
     __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -250,14 +265,7 @@ PF_DECL_LAUNCH(10) PF_DECL_LAUNCH(11) PF_DECL_LAUNCH(12) PF_DECL_LAUNCH(13) PF_D
 // the (ciphertext, limb) groups g = x (mod 8) and runs a group's `fanout` products back to back, so the ciphertext limb
 // they share comes from HBM once and from that XCD's L2 after.
 // The 64 registers of the kept plaintext put the kernel at two workgroups per CU whatever it does, so up to N = 8192 it takes
-// the 80 KiB of LDS that leaves it and exchanges through a whole-polynomial buffer (one round and two barriers per exchange
-// instead of two and four; twiddles requested ahead of the exchange).
-template <class A> struct WholeXchg : A { static constexpr bool HALF_EXCHANGE_OK = false; };
-template <class A> struct ArithOf<WholeXchg<A>> {
-    static __device__ __forceinline__ WholeXchg<A> make(const LimbDev &l) { return WholeXchg<A>{ArithOf<A>::make(l)}; }
-    static __device__ __forceinline__ auto fwd(const void *t, const LimbDev &l) { return ArithOf<A>::fwd(t, l); }
-    static __device__ __forceinline__ auto inv(const void *t, const LimbDev &l) { return ArithOf<A>::inv(t, l); }
-};
+// the 80 KiB of LDS that leaves it and exchanges through a whole-polynomial buffer (WholeXchg).
 template <int LOGN, class A> struct RowsCtptArith { using type = A; };
 template <class A> struct RowsCtptArith<13, A> { using type = WholeXchg<A>; };
 template <class A> struct RowsCtptArith<12, A> { using type = WholeXchg<A>; };
