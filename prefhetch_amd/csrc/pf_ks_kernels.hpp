@@ -14,17 +14,23 @@ struct KsArgs {
     uint64_t *acc;           // [Bs][2][K][N] products: NTT form after step 2, coefficient form after the inverse NTT
     uint64_t *ct;            // [Bs][2][D][N] ciphertext the switched polynomial is added into (step 4)
     uint32_t D, K, logn;
+    uint32_t nb;             // ciphertexts in this round of the workspace (Bs)
 };
 
 // step 2: acc[b][c][J] = sum_I x[b][I][J] . ksk[I][c][J]  (mod m_J), accumulated in 128 bits like SEAL's lazy sum
 // (D <= 63 summands of < 2^122 each), reduced once.  One block per (b, J, 2048-coefficient chunk), 16 B per lane.
+// Block order: the key slice of a (J, chunk) unit is what the nb ciphertexts of the round share (the key is 126 MB at config 5,
+// four times the L2s together), so XCD x (blocks x, x + 8, ...) takes the units u = x (mod 8) and runs a unit's nb ciphertexts
+// back to back: the slice comes from memory once and from that XCD's L2 for the other nb - 1.  (With b outermost every
+// ciphertext re-read the whole key from the Infinity Cache.)
 __global__ void __launch_bounds__(256) k_ks_mac(KsArgs p) {
     const uint32_t chunk_log = p.logn < 11 ? p.logn : 11;
     const uint32_t chunks = 1u << (p.logn - chunk_log);
-    const uint32_t ch = blockIdx.x % chunks;
-    const size_t bj = blockIdx.x / chunks;
-    const uint32_t J = (uint32_t)(bj % p.K);
-    const size_t b = bj / p.K;
+    const uint32_t xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const uint32_t unit = (seq / p.nb) * 8 + xcd;               // J * chunks + chunk
+    if (unit >= p.K * chunks) return;
+    const size_t b = seq % p.nb;
+    const uint32_t ch = unit % chunks, J = unit / chunks;
     const LimbDev &lm = p.limbs[J];
     const ArithU64 ar{lm.q, lm.two_q, lm.ratio0, lm.ratio1};
     const size_t N = (size_t)1 << p.logn;

@@ -428,8 +428,8 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
         pf_status st = dispatch_logn(c, arith, 3, 0, a, nb * D * K, s);
         if (st != PF_OK) return st;
         // 2. multiply-accumulate with the key
-        KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn};
-        hipLaunchKernelGGL(k_ks_mac, dim3((unsigned)(nb * K * chunks)), dim3(256), 0, s, k);
+        KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn, (uint32_t)nb};
+        hipLaunchKernelGGL(k_ks_mac, dim3((unsigned)((K * chunks + 7) / 8 * 8 * nb)), dim3(256), 0, s, k);
         // 3. back to coefficient form, all K limbs of both components
         NttArgs ai{c->d_limbs, c->d_tables, acc, acc, nullptr, 0, K, 0, 0};
         st = dispatch_logn(c, arith, 1, 0, ai, nb * 2 * K, s);
