@@ -534,6 +534,9 @@ inline bool u64_lazy_ok(uint64_t q, int logn) { return logn <= 15 && q < (1ull <
 // The butterfly of local bit kb pairs registers k0 (bit kb clear) and k0 | 2^kb; its twiddle is entry
 // m + (i >> (b+1)) for the global bit b = a + kb and i the coefficient index of register k0.
 
+#ifndef PF_TW_AHEAD
+#define PF_TW_AHEAD 1          // 64-bit back-end: per-lane twiddles requested one batch of butterflies ahead of their use
+#endif
 constexpr int NBATCH = 4;     // independent butterflies issued together (covers the FP64 dependent-issue latency)
 
 // The twiddles of one pass, fetched up front so the caller can issue them BEFORE the exchange that precedes
@@ -596,16 +599,42 @@ template <class G, class A, int PASS, int KB>
 PF_HD void fwd_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, PASS> &T) {
     using V = typename A::V;
     using TwR = typename A::TwR;
+    // Twiddles fetched where they are used (16-byte entries, per-lane addresses: passes > 0 of the 64-bit back-end) are requested
+    // one batch AHEAD: asked for and waited for inside the same batch, each of the ~31 distinct fetches of a pass cost a full
+    // L2 round trip with two waves per SIMD to hide it (pass 1 of N = 32768 took 42 k cycles against 24 k for pass 0).
+    constexpr bool AHEAD = PassTw<G, A, PASS>::LAZY && PASS != 0 && PF_TW_AHEAD;
+    typename A::Tw nxt[NBATCH], nx2[NBATCH];
+    if constexpr (AHEAD) {
+#pragma unroll
+        for (int i = 0; i < NBATCH; ++i) nxt[i] = T.fetch(KB, i >> KB);
+        if constexpr (PF_TW_AHEAD >= 2 && NBATCH < G::R / 2) {
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) nx2[i] = T.fetch(KB, (NBATCH + i) >> KB);
+        }
+    }
 #pragma unroll
     for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
         V ys[NBATCH];
         TwR ts[NBATCH];
+        typename A::Tw cur[NBATCH];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) { cur[i] = nxt[i]; if constexpr (PF_TW_AHEAD >= 2) nxt[i] = nx2[i]; }
+        }
         PF_SCHED_FENCE();                 // keeps the twiddle resolves (w * 1/q) of later batches from piling up in registers
+        if constexpr (AHEAD) {
+            constexpr int D = PF_TW_AHEAD >= 2 ? 2 : 1;
+            if (bb + D * NBATCH < G::R / 2) {
+#pragma unroll
+                for (int i = 0; i < NBATCH; ++i) (D == 2 ? nx2[i] : nxt[i]) = T.fetch(KB, (bb + D * NBATCH + i) >> KB);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NBATCH; ++i) {
             const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
             ys[i] = r[k0 | (1 << KB)];
-            ts[i] = T.get(ar, KB, b >> KB);
+            if constexpr (AHEAD) ts[i] = ar.resolve(cur[i]);
+            else ts[i] = T.get(ar, KB, b >> KB);
         }
         ar.template mul_tw_n<NBATCH, PASS == 0>(ys, ts);
         V xs[NBATCH], yo[NBATCH];
@@ -634,17 +663,35 @@ PF_HD void inv_stage(typename A::V (&r)[G::R], const A &ar, const PassTw<G, A, P
     using V = typename A::V;
     using TwR = typename A::TwR;
     if constexpr (KB <= KB_HI) {
+        constexpr bool AHEAD = PassTw<G, A, PASS>::LAZY && PASS != 0 && PF_TW_AHEAD;     // see fwd_stage
+        typename A::Tw nxt[NBATCH];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) nxt[i] = T.fetch(KB, i >> KB);
+        }
 #pragma unroll
         for (int bb = 0; bb < G::R / 2; bb += NBATCH) {
             V ds[NBATCH];
             TwR ts[NBATCH];
+            typename A::Tw cur[NBATCH];
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int i = 0; i < NBATCH; ++i) cur[i] = nxt[i];
+            }
             PF_SCHED_FENCE();
+            if constexpr (AHEAD) {
+                if (bb + NBATCH < G::R / 2) {
+#pragma unroll
+                    for (int i = 0; i < NBATCH; ++i) nxt[i] = T.fetch(KB, (bb + NBATCH + i) >> KB);
+                }
+            }
             V xs[NBATCH], yi[NBATCH];
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
                 const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
                 xs[i] = r[k0]; yi[i] = r[k0 | (1 << KB)];
-                ts[i] = T.get(ar, KB, b >> KB);
+                if constexpr (AHEAD) ts[i] = ar.resolve(cur[i]);
+                else ts[i] = T.get(ar, KB, b >> KB);
             }
             ar.template inv_split_n<KB, NBATCH>(xs, yi, ds);
 #pragma unroll
