@@ -424,8 +424,13 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     for (size_t b0 = 0; b0 < B; b0 += sub) {
         const size_t nb = B - b0 < sub ? B - b0 : sub;
         // 1. digit NTTs: x[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)
-        NttArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, nullptr, 0, K, 0, D};
-        pf_status st = dispatch_logn(c, arith, 3, 0, a, nb * D * K, s);
+        NttArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, nullptr, nb * D * K, K, 0, D};
+        size_t ks_grid = nb * D * K;
+        if (c->logn >= 15 && PF_KS_PERSIST) {               // persistent workgroups, one per CU, a multiple of K of them (k_ks_ntt)
+            const size_t per = ((size_t)c->num_cus / K) * K;
+            if (per && per < ks_grid) ks_grid = per;
+        }
+        pf_status st = dispatch_logn(c, arith, 3, 0, a, ks_grid, s);
         if (st != PF_OK) return st;
         // 2. multiply-accumulate with the key
         KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn, (uint32_t)nb};

@@ -51,6 +51,10 @@ template <bool LAZY> struct ArithOf<ArithU64T<LAZY>> {
 #define PF_WG_PER_CU(LOGN, A) ((160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8) > 3 ? 3 : (160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8))
 #define PF_WAVES_PER_SIMD(LOGN, A) ((PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256) < 2 ? 2 : (PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256))
 
+#ifndef PF_KS_PERSIST
+#define PF_KS_PERSIST 0        // experiment, see k_ks_ntt: measured 24.1 ms per 256 key switches against 23.5 (the loop costs 124 B of scratch per thread)
+#endif
+
 struct WgSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 
 // One workgroup = one limb-polynomial (blockIdx.x).  Consecutive block ids cycle through the limbs, and blocks
@@ -77,6 +81,22 @@ template <int LOGN, class A>
 __global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ks_ntt(NttArgs p) {
     using G = Geo<LOGN>;
     __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
+    if constexpr (LOGN >= 15 && PF_KS_PERSIST) {
+        // One workgroup owns a CU at this degree (128 KiB of LDS), so nothing else covers its load and store phases: the
+        // workgroup stays and walks the transforms id, id + gridDim, ... (n_pairs of them) -- the loads of the next one are issued
+        // while the stores of the last one drain.  gridDim is a multiple of the modulus count, so a workgroup keeps its limb.
+        for (size_t id = blockIdx.x; id < p.n_pairs; id += gridDim.x) {
+            int tid = (int)threadIdx.x;
+            PF_LAUNDER(tid);                             // per-iteration addresses: hoisted out of the loop they would cost ~80 VGPRs
+            const uint32_t J = (uint32_t)(id % p.L);
+            const size_t digit = id / p.L;
+            const LimbDev &lm = p.limbs[J];
+            const A ar = ArithOf<A>::make(lm);
+            body_ntt_fwd_mod<G, A>(ar, ArithOf<A>::fwd(p.tables, lm), p.src + digit * G::N, p.dst + id * G::N, lm.q, lm.ratio1, lds, tid,
+                                   WgSync{});
+        }
+        return;
+    }
     const size_t id = blockIdx.x;
     const uint32_t J = (uint32_t)(id % p.L);
     const size_t digit = id / p.L;                       // b * D + I
