@@ -80,12 +80,13 @@ class Server {
                                     uint64_t *result_ct_host, std::array<std::array<float, COARSE_PROBE>, NQUERY> &row_norms) const;
     // The private form of preciseVectorPIR (include/client/pir.h: SealPIR-style retrieval built from pf_ct_pt_mul and
     // pf_key_switch): the ids stay with the client.  Ring degree 8192, BFVDefault(8192) data primes + its special prime,
-    // plaintext modulus PIR_PLAIN_MODULUS.  `count` query ciphertexts [count][2][4][8192] in, `count` replies out; the client's
+    // plaintext modulus PIR_PLAIN_MODULUS.  `count` query ciphertexts [count][2][4][8192] in, `count` x pirCols() reply ciphertexts out (a retrieval's columns together); the client's
     // Galois keys for the pirLevels() expansion rounds (pir::galois_elements), [levels][4][2][5][8192] words in
     // pf_key_switch's layout.  The packed database is built from the base rows on first use.
     static constexpr uint64_t PIR_PLAIN_MODULUS = 65537;
     size_t pirRows() const;
     uint32_t pirLevels() const;
+    size_t pirCols() const;           // ciphertexts per retrieval in the reply (pir::Layout::n_cols: 4 at 1M rows)
     void preciseVectorPIRPrivateHost(const uint64_t *query_ct_host, size_t count, const uint64_t *galois_keys_host, uint64_t *reply_ct_host) const;
     // The executed flat-L2 shortlist of the protocol (client sort_nearest_centroids, src/client/client_lib.cpp:50-81)
     // on the server's IndexFlatL2 over the centroids: top-NPROBE centroid ids (and squared distances) per query.

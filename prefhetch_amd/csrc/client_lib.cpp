@@ -284,7 +284,7 @@ void get_precise_vectors_pir_private(const PreciseRanking &nearest_precise_vecto
     if (results_per_query > (size_t)K) throw std::invalid_argument("private retrieval: at most K rows per query");
     const wire::Json lay_json = wire::parse(transport().post("pir-layout", "{}"));
     const pir::Layout lay = pir::Layout::make(ctx.N(), (uint32_t)D, (size_t)lay_json.at("rows").as_int());
-    if ((int64_t)lay.levels != lay_json.at("levels").as_int() || (int64_t)ctx.N() != lay_json.at("ringDegree").as_int() ||
+    if ((int64_t)lay.levels != lay_json.at("levels").as_int() || (int64_t)lay.n_cols != lay_json.at("cols").as_int() || (int64_t)ctx.N() != lay_json.at("ringDegree").as_int() ||
         (int64_t)ctx.t() != lay_json.at("plainModulus").as_int())
         throw std::invalid_argument("private retrieval: the server packs its rows for other parameters");
     const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, key_words = L * 2 * (L + 1) * N;
@@ -314,13 +314,15 @@ void get_precise_vectors_pir_private(const PreciseRanking &nearest_precise_vecto
         const wire::Json &blob = resp.at("replyCiphertexts");
         if (blob.kind != wire::Json::String) throw wire::TypeError("replyCiphertexts must be a base64 string");
         const std::vector<uint8_t> raw = wire::base64_decode(blob.s);
-        if (raw.size() != results_per_query * per * 8) throw std::out_of_range("replyCiphertexts has the wrong size");
+        const size_t n_reply = results_per_query * lay.n_cols;                         // a retrieval's columns together
+        if (raw.size() != n_reply * per * 8) throw std::out_of_range("replyCiphertexts has the wrong size");
         bfv::Ciphertexts rct;
-        rct.count = results_per_query;
-        rct.data = bfv::DeviceWords(ctx.params().device, results_per_query * per);
-        rct.data.upload(reinterpret_cast<const uint64_t *>(raw.data()), results_per_query * per);
+        rct.count = n_reply;
+        rct.data = bfv::DeviceWords(ctx.params().device, n_reply * per);
+        rct.data.upload(reinterpret_cast<const uint64_t *>(raw.data()), n_reply * per);
         decryptor.decrypt(rct, back);
-        for (size_t j = 0; j < results_per_query; ++j) pir::decode_row(lay, back.data() + j * N, (size_t)query_results_idx[i][j], query_results[i][j].data());
+        for (size_t j = 0; j < results_per_query; ++j)
+            pir::decode_row(lay, back.data() + j * lay.n_cols * N, (size_t)query_results_idx[i][j], query_results[i][j].data());
     }
 }
 

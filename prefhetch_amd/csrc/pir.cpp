@@ -34,19 +34,22 @@ uint64_t inv_pow2(uint32_t levels, uint64_t t) {
 
 }  // namespace
 
-Layout Layout::make(uint32_t N, uint32_t d, size_t n_rows) {
+Layout Layout::make(uint32_t N, uint32_t d, size_t n_rows, size_t max_sel) {
     Layout l;
     if (d == 0 || 2 * (size_t)d > N) throw std::invalid_argument("pir: a row (2 coefficients per value) must fit one polynomial");
     l.N = N; l.d = d; l.n_rows = n_rows;
     l.rows_per_poly = N / (2 * d);
     l.n_polys = (n_rows + l.rows_per_poly - 1) / l.rows_per_poly;
     if (l.n_polys == 0) l.n_polys = 1;
-    while ((size_t{1} << l.levels) < l.n_polys) ++l.levels;
-    if ((size_t{1} << l.levels) > N) throw std::invalid_argument("pir: more than N polynomials need a second query dimension (not built)");
+    const size_t cap = max_sel && max_sel < N ? max_sel : N;
+    l.n_sel = l.n_polys < cap ? l.n_polys : cap;
+    l.n_cols = (l.n_polys + l.n_sel - 1) / l.n_sel;
+    while ((size_t{1} << l.levels) < l.n_sel) ++l.levels;
     return l;
 }
 
-Database::Database(const bfv::Context &ctx, const float *rows, size_t n_rows, uint32_t d) : m_Layout(Layout::make(ctx.N(), d, n_rows)) {
+Database::Database(const bfv::Context &ctx, const float *rows, size_t n_rows, uint32_t d, size_t max_sel)
+    : m_Layout(Layout::make(ctx.N(), d, n_rows, max_sel)) {
     if (ctx.t() <= 65536) throw std::invalid_argument("pir: plaintext modulus must exceed 2^16 (two 16-bit halves per value)");
     const size_t N = ctx.N(), L = ctx.L(), P = m_Layout.n_polys;
     // coefficients are below t < every q_l: the lift to the ciphertext moduli repeats the value in each limb
@@ -107,14 +110,15 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
     const Layout &lay = db.layout();
     const size_t N = ctx.N(), L = ctx.L(), per = 2 * L * N, P = lay.n_polys;
     const int dev = ctx.params().device;
-    reply.count = query.count;
+    const size_t S = lay.n_sel, C = lay.n_cols;
+    reply.count = query.count * C;
     if (query.count == 0) return;
-    if (reply.data.words() < query.count * per) reply.data = bfv::DeviceWords(dev, query.count * per);
+    if (reply.data.words() < reply.count * per) reply.data = bfv::DeviceWords(dev, reply.count * per);
     Database::Workspace &w = db.workspace();
     bfv::Ciphertexts &one = w.one, &sel = w.sel;
     one.count = 1;
     if (one.data.words() < per) one.data = bfv::DeviceWords(dev, per);
-    if (w.prod.words() < P * per) w.prod = bfv::DeviceWords(dev, P * per);
+    if (w.prod.words() < S * per) w.prod = bfv::DeviceWords(dev, S * per);
     bfv::DeviceWords &prod = w.prod;
     const bool trace = std::getenv("PF_PIR_TRACE") != nullptr;
     auto stamp = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
@@ -129,17 +133,18 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
         check(pf_memcpy_d2d(dev, one.data.ptr(), query.data.ptr() + q * per, per * 8, nullptr), "d2d");
         expand(ctx, one, keys, lay.levels, sel, &w);
         stamp("expand", t0);
-        // products in NTT form, summed there by halving (one launch per halving), one inverse transform at the end
-        check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt(), P, prod.ptr(), P, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
-        stamp("products", t0);
-        for (size_t n = P; n > 1;) {
-            const size_t half = n / 2, keep = n - half;                                  // fold the last `half` onto the first `half`
-            check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
-            n = keep;
+        // per column: products in NTT form, summed there by halving (one launch per halving), one inverse transform at the end
+        for (size_t c = 0; c < C; ++c) {
+            const size_t cnt = P - c * S < S ? P - c * S : S;
+            check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt() + c * S * L * N, cnt, prod.ptr(), cnt, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
+            for (size_t n = cnt; n > 1;) {
+                const size_t half = n / 2, keep = n - half;                              // fold the last `half` onto the first `half`
+                check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
+                n = keep;
+            }
+            check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), reply.data.ptr() + (q * C + c) * per, 2 * L, nullptr), "pf_ntt_inverse_to");
         }
-        uint64_t *out = reply.data.ptr() + q * per;
-        check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), out, 2 * L, nullptr), "pf_ntt_inverse_to");
-        stamp("sum + inv", t0);
+        stamp("columns", t0);
     }
     check(pf_stream_synchronize(dev, nullptr), "sync");
 }
@@ -147,10 +152,11 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
 void encode_query(const Layout &lay, uint64_t t, size_t row, uint64_t *plain_out) {
     if (row >= lay.n_rows) throw std::out_of_range("pir::encode_query: no such row");
     std::memset(plain_out, 0, (size_t)lay.N * 8);
-    plain_out[lay.poly_of(row)] = inv_pow2(lay.levels, t);
+    plain_out[lay.sel_of(row)] = inv_pow2(lay.levels, t);
 }
 
 void decode_row(const Layout &lay, const uint64_t *plain, size_t row, float *out) {
+    plain += lay.col_of(row) * lay.N;                                                    // the column's plaintext
     const size_t c0 = (size_t)lay.slot_of(row) * 2 * lay.d;
     for (uint32_t i = 0; i < lay.d; ++i) {
         const uint32_t bits = (uint32_t)(plain[c0 + 2 * i] & 0xFFFFu) | ((uint32_t)(plain[c0 + 2 * i + 1] & 0xFFFFu) << 16);

@@ -431,6 +431,12 @@ uint32_t Server::pirLevels() const {
     return pir::Layout::make(ENC_RING_DEGREE, static_cast<uint32_t>(PRECISE_VECTOR_DIMENSIONS), m_Impl->nb).levels;
 }
 
+size_t Server::pirCols() const {
+    std::lock_guard<std::mutex> g(m_Impl->lock);
+    m_Impl->require_ready();
+    return pir::Layout::make(ENC_RING_DEGREE, static_cast<uint32_t>(PRECISE_VECTOR_DIMENSIONS), m_Impl->nb).n_cols;
+}
+
 void Server::preciseVectorPIRPrivateHost(const uint64_t *query_ct_host, size_t count, const uint64_t *galois_keys_host, uint64_t *reply_ct_host) const {
     if (count == 0) return;
     if (!query_ct_host || !galois_keys_host || !reply_ct_host) throw std::invalid_argument("preciseVectorPIRPrivateHost: null buffer");
@@ -452,7 +458,7 @@ void Server::preciseVectorPIRPrivateHost(const uint64_t *query_ct_host, size_t c
     query.data = bfv::DeviceWords(im.device, count * per);
     query.data.upload(query_ct_host, count * per);
     pir::answer(ps.ctx, ps.db, query, keys, reply);
-    reply.data.download(reply_ct_host, count * per);
+    reply.data.download(reply_ct_host, reply.count * per);                             // count x n_cols ciphertexts
 }
 
 void Server::nearestCentroids(const std::array<std::array<float, PRECISE_VECTOR_DIMENSIONS>, NQUERY> &precise_query,

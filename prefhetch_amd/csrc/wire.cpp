@@ -402,7 +402,7 @@ std::string handle_precise_search_encrypted(const Server &server, const std::str
 
 // ---- private row retrieval (include/client/pir.h) -------------------------------------------------------------
 std::string handle_pir_layout(const Server &server) {
-    return "{\"rows\":" + std::to_string(server.pirRows()) + ",\"levels\":" + std::to_string(server.pirLevels()) +
+    return "{\"rows\":" + std::to_string(server.pirRows()) + ",\"levels\":" + std::to_string(server.pirLevels()) + ",\"cols\":" + std::to_string(server.pirCols()) +
            ",\"ringDegree\":" + std::to_string(Server::ENC_RING_DEGREE) + ",\"plainModulus\":" + std::to_string(Server::PIR_PLAIN_MODULUS) + "}";
 }
 
@@ -436,7 +436,7 @@ std::string handle_precise_vector_pir_private(const Server &server, const std::s
     if (blob.kind != Json::String) throw TypeError("queryCiphertexts must be a base64 string");
     const std::vector<uint8_t> raw = base64_decode(blob.s);
     if (raw.size() != count * per * 8) throw std::out_of_range("queryCiphertexts: expected " + std::to_string(count * per * 8) + " bytes, got " + std::to_string(raw.size()));
-    std::vector<uint64_t> in(count * per), out(count * per);
+    std::vector<uint64_t> in(count * per), out(count * server.pirCols() * per);
     std::memcpy(in.data(), raw.data(), raw.size());
     server.preciseVectorPIRPrivateHost(in.data(), count, keys.data(), out.data());
     return "{\"replyCiphertexts\":\"" + base64_encode(out.data(), out.size() * 8) + "\"}";

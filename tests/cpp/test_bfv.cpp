@@ -320,6 +320,27 @@ int main() {
         bool threw = false;
         try { pir::encode_query(lay, ctx.t(), n_rows, plain.data()); } catch (const std::out_of_range &) { threw = true; }
         EXPECT(threw);
+        // more polynomials than one query selects among (forced here: 8 per column -> 4 columns, 3 expansion rounds; 1M rows at
+        // N = 8192 is the same with 8192 per column): one reply ciphertext per column, the client keeps its own
+        {
+            pir::Database db4(ctx, base.data(), n_rows, d, 8);
+            const pir::Layout &l4 = db4.layout();
+            EXPECT(l4.n_sel == 8 && l4.n_cols == 4 && l4.levels == 3);
+            const size_t want4[3] = {7, 8 * 32 + 5, 999};                               // columns 0, 1 and 3
+            std::vector<uint64_t> p4(3 * ctx.N()), b4;
+            for (size_t i = 0; i < 3; ++i) pir::encode_query(l4, ctx.t(), want4[i], p4.data() + i * ctx.N());
+            bfv::Ciphertexts q4, r4;
+            enc.encrypt(p4.data(), 3, q4);
+            pir::answer(ctx, db4, q4, keys, r4);
+            EXPECT(r4.count == 12);
+            dec.decrypt(r4, b4);
+            for (size_t i = 0; i < 3; ++i) {
+                float row[128];
+                pir::decode_row(l4, b4.data() + i * l4.n_cols * ctx.N(), want4[i], row);
+                EXPECT(std::memcmp(row, base.data() + want4[i] * d, sizeof row) == 0);
+            }
+            std::printf("PIR with 4 columns: 3 rows retrieved, 4 reply ciphertexts each\n");
+        }
     }
     if (fails) std::printf("test_bfv: %d FAILURES\n", fails);
     else std::printf("test_bfv: OK\n");

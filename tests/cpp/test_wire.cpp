@@ -123,7 +123,15 @@ static int selftest() {
         const pir::Layout lay = pir::Layout::make(8192, 128, 10000);
         EXPECT(lay.rows_per_poly == 32 && lay.n_polys == 313 && lay.levels == 9 && lay.poly_of(9999) == 312 && lay.slot_of(9999) == 15);
         EXPECT(pir::Layout::make(8192, 128, 1).levels == 0 && pir::Layout::make(8192, 128, 33).levels == 1 && pir::Layout::make(8192, 64, 8192u * 64).levels == 13);
-        EXPECT(throws<std::invalid_argument>([] { pir::Layout::make(8192, 128, 8192u * 32 + 1); }));   // more than N polynomials
+        {                                                                                              // more than N polynomials: columns
+            const pir::Layout big = pir::Layout::make(8192, 128, 8192u * 32 + 1);
+            EXPECT(big.n_polys == 8193 && big.n_sel == 8192 && big.n_cols == 2 && big.levels == 13);
+            EXPECT(big.sel_of(8192u * 32) == 0 && big.col_of(8192u * 32) == 1 && big.col_of(8192u * 32 - 1) == 0 && big.sel_of(8192u * 32 - 1) == 8191);
+            const pir::Layout sift = pir::Layout::make(8192, 128, 1000000);
+            EXPECT(sift.n_polys == 31250 && sift.n_cols == 4 && sift.levels == 13);
+            const pir::Layout forced = pir::Layout::make(8192, 128, 1000, 8);
+            EXPECT(forced.n_polys == 32 && forced.n_sel == 8 && forced.n_cols == 4 && forced.levels == 3);
+        }
         EXPECT(throws<std::invalid_argument>([] { pir::Layout::make(1024, 1024, 4); }));              // a row does not fit a polynomial
         const std::vector<uint32_t> elts = pir::galois_elements(8192, 9);
         EXPECT(elts.size() == 9 && elts[0] == 8193 && elts[1] == 4097 && elts[8] == 33);

@@ -1,6 +1,6 @@
 // time_pir.cpp -- the private row retrieval (include/client/pir.h) at size: build the database, expand one query, answer
 // `n_query` of them, check the rows bit for bit and print the times.  Usage: time_pir [n_rows (default 262144: the most one
-// query dimension holds at N = 8192, d = 128)] [n_query (default 2)].  Built by `make -C prefhetch_amd/csrc time_pir`.
+// column holds at N = 8192, d = 128; 1000000 = the reference's base, 4 columns)] [n_query (default 2)].  Built by `make -C prefhetch_amd/csrc time_pir`.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,14 +53,14 @@ int main(int argc, char **argv) {
     int bad = 0;
     for (size_t i = 0; i < n_query; ++i) {
         float row[128];
-        pir::decode_row(lay, back.data() + i * ctx.N(), wanted[i], row);
+        pir::decode_row(lay, back.data() + i * lay.n_cols * ctx.N(), wanted[i], row);
         bad += std::memcmp(row, base.data() + wanted[i] * d, sizeof row) != 0;
     }
-    const int budget = dec.invariant_noise_budget(reply, n_query - 1);
-    std::printf("{\"n_rows\": %zu, \"d\": %u, \"polynomials\": %zu, \"levels\": %u, \"database_build_ms\": %.1f, \"galois_keygen_ms\": %.1f, "
+    const int budget = dec.invariant_noise_budget(reply, reply.count - 1);
+    std::printf("{\"n_rows\": %zu, \"d\": %u, \"polynomials\": %zu, \"levels\": %u, \"columns\": %zu, \"database_build_ms\": %.1f, \"galois_keygen_ms\": %.1f, "
                 "\"expand_ms\": %.2f, \"answer_ms_per_query\": %.2f, \"key_switches_per_query\": %zu, \"products_per_query\": %zu, "
                 "\"rows_bit_identical\": %s, \"reply_noise_budget_bits\": %d, \"query_bytes\": %zu, \"reply_bytes\": %zu}\n",
-                n_rows, d, lay.n_polys, lay.levels, db_ms, key_ms, expand_ms, answer_ms, (size_t{1} << lay.levels) - 1, lay.n_polys,
-                bad ? "false" : "true", budget, 2 * ctx.L() * ctx.N() * 8, 2 * ctx.L() * ctx.N() * 8);
+                n_rows, d, lay.n_polys, lay.levels, lay.n_cols, db_ms, key_ms, expand_ms, answer_ms, (size_t{1} << lay.levels) - 1, lay.n_polys,
+                bad ? "false" : "true", budget, 2 * ctx.L() * ctx.N() * 8, lay.n_cols * 2 * ctx.L() * ctx.N() * 8);
     return bad || budget <= 0;
 }
