@@ -159,6 +159,14 @@ pf_status pf_pack_rows(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size
 pf_status pf_pack_rows_ntt(pf_ctx *ctx, const pf_flat *idx, const int64_t *ids, size_t n_polys, uint32_t rows_per_poly,
                            uint64_t *out, pf_stream stream);
 
+/* Sums of ciphertext x plaintext products, operands and results in NTT form: with groups of `chunk` consecutive plaintexts,
+ *     out[g] = sum_{p in group g} ct_ntt[p mod n_ct] . pt_ntt[p],     g < ceil(n_pt / chunk),   chunk divides n_ct.
+ * ct_ntt [n_ct][2][L][N], pt_ntt [n_pt][L][N], out [ceil(n_pt / chunk)][2][L][N] (must not alias the operands).  One pass over
+ * the operands with 128-bit lazy sums (PF_ERR_UNSUPPORTED when chunk * q^2 could reach 2^128): Evaluator::multiply_plain +
+ * add_many of SealPIR's answer step without the products ever existing in memory.  No allocation, no synchronisation. */
+pf_status pf_ct_pt_dot(pf_ctx *ctx, const uint64_t *ct_ntt, size_t n_ct, const uint64_t *pt_ntt, size_t n_pt, size_t chunk, uint64_t *out,
+                       pf_stream stream);
+
 /* The server side of the encrypted precise search in ONE kernel: out[b] = ct[b / fanout] x pack(ids[b]), b < B, with the
  * plaintext of product b packed from the base rows (pf_pack_rows), transformed and multiplied into both components of
  * its ciphertext inside one workgroup per (product, limb) -- the plaintexts never exist in memory, in either form.

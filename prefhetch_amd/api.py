@@ -213,6 +213,15 @@ class RnsContext:
         check(fn(self._h, flat._h, pi, n_polys, rows, po, _stream(self.device)), "pf_pack_rows_ntt" if ntt else "pf_pack_rows")
         return out
 
+    def ct_pt_dot(self, ct_ntt, pt_ntt, chunk):
+        """out[g] = sum over the plaintexts p of chunk g of ct_ntt[p mod n_ct] . pt_ntt[p], all in NTT form: ct_ntt [n_ct,2,L,N],
+        pt_ntt [n_pt,L,N] -> [ceil(n_pt / chunk),2,L,N]; chunk divides n_ct."""
+        n_ct, n_pt = ct_ntt.numel() // (2 * self.L * self.N), pt_ntt.numel() // (self.L * self.N)
+        out = torch.empty((-(-n_pt // int(chunk)), 2, self.L, self.N), dtype=torch.int64, device=self.device)
+        pc, pp, po = (_req(t, torch.int64, self.device_index, n) for t, n in ((ct_ntt, "ct_ntt"), (pt_ntt, "pt_ntt"), (out, "out")))
+        check(lib.pf_ct_pt_dot(self._h, pc, n_ct, pp, n_pt, int(chunk), po, _stream(self.device)), "pf_ct_pt_dot")
+        return out
+
     def ct_rows_mul(self, ct_ntt, flat, ids, fanout, out=None):
         """out[b] = ct_ntt[b // fanout] x pack(ids[b]) in one kernel (pack_rows(ntt=True) + ct_pt_mul_fanout(IN_NTT), bit for
         bit, without the plaintexts ever existing in memory): ct_ntt [ceil(B/fanout),2,L,N] NTT form, ids [B, rows_per_poly]

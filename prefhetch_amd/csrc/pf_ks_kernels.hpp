@@ -209,4 +209,53 @@ __global__ void __launch_bounds__(256) k_mul_monomial(MonoArgs p) {
     p.out[poly * N + c] = (i >= N && v) ? q - v : v;
 }
 
+// ---- sum of ciphertext x plaintext products, everything in NTT form (pf_ct_pt_dot) --------------------------------------
+// out[g] = sum over the plaintexts p of chunk g (p in [g * chunk, min((g + 1) * chunk, n_pt))) of ct[p % n_ct] . pt[p]; chunk divides
+// n_ct, so a chunk never wraps.  The private retrieval's answer: sum_k selection_k x database_k per column, split 16 ways along k
+// for parallelism.  One block per (g, limb, 512 coefficients), both components per thread (they share the plaintext value), 128-bit
+// lazy sums reduced once like k_ks_mac (the host checks chunk * q^2 < 2^128).  Streams ct and pt once: 40 B per coefficient and term.
+struct DotArgs {
+    const LimbDev *limbs;
+    const uint64_t *ct, *pt; uint64_t *out;
+    uint32_t L, logn;
+    uint64_t n_ct, n_pt, chunk;
+};
+
+__global__ void __launch_bounds__(256) k_ct_pt_dot(DotArgs p) {
+    const size_t N = (size_t)1 << p.logn;
+    const uint32_t cpp = (uint32_t)(N / 512);
+    const uint32_t ch = blockIdx.x % cpp, limb = (blockIdx.x / cpp) % p.L;
+    const size_t g = blockIdx.x / (cpp * p.L);
+    const LimbDev &lm = p.limbs[limb];
+    const ArithU64 ar{lm.q, lm.two_q, lm.ratio0, lm.ratio1};
+    const size_t n2 = (size_t)ch * 256 + threadIdx.x, half = N / 2;                       // index of a coefficient PAIR
+    const size_t p0 = g * p.chunk, p1 = p0 + p.chunk < p.n_pt ? p0 + p.chunk : p.n_pt, k0 = p0 % p.n_ct;
+    const ulonglong2 *pt2 = reinterpret_cast<const ulonglong2 *>(p.pt) + ((p0 * p.L + limb) * half + n2);
+    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(p.ct) + ((k0 * 2 * p.L + limb) * half + n2);
+    const size_t pt_step = (size_t)p.L * half, ct_step = 2 * (size_t)p.L * half, comp = (size_t)p.L * half;
+    uint64_t lo[2][2] = {{0, 0}, {0, 0}}, hi[2][2] = {{0, 0}, {0, 0}};                    // [component][element]
+#pragma unroll 4
+    for (size_t j = 0; j < p1 - p0; ++j) {
+        const ulonglong2 pv = pt2[j * pt_step], a = c2[j * ct_step], b = c2[j * ct_step + comp];
+        const uint64_t ps[2] = {pv.x, pv.y}, xs[2][2] = {{a.x, a.y}, {b.x, b.y}};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint64_t pl = xs[c][e] * ps[e], ph = mulhi64(xs[c][e], ps[e]);
+                const uint64_t s = lo[c][e] + pl;
+                hi[c][e] += ph + (s < pl ? 1 : 0);
+                lo[c][e] = s;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        ulonglong2 o;
+        const uint64_t r0 = ar.barrett128(lo[c][0], hi[c][0]), r1 = ar.barrett128(lo[c][1], hi[c][1]);
+        o.x = r0 >= lm.q ? r0 - lm.q : r0;
+        o.y = r1 >= lm.q ? r1 - lm.q : r1;
+        reinterpret_cast<ulonglong2 *>(p.out)[((g * 2 + c) * p.L + limb) * half + n2] = o;
+    }
+}
+
 }  // namespace pf

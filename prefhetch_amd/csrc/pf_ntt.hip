@@ -380,6 +380,27 @@ pf_status pf_poly_addsub_monomial(pf_ctx *c, const uint64_t *a, const uint64_t *
     return PF_OK;
 }
 
+pf_status pf_ct_pt_dot(pf_ctx *c, const uint64_t *ct_ntt, size_t n_ct, const uint64_t *pt_ntt, size_t n_pt, size_t chunk, uint64_t *out, pf_stream stream) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (n_pt == 0) return PF_OK;
+    if (!ct_ntt || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (n_ct == 0 || chunk == 0 || n_ct % chunk) return fail(PF_ERR_INVALID_ARG, "pf_ct_pt_dot: chunk must divide the ciphertext count");
+    if (out == ct_ntt || out == pt_ntt) return fail(PF_ERR_INVALID_ARG, "pf_ct_pt_dot: out must not alias the operands");
+    unsigned bits = 0, lc = 0;
+    for (uint32_t l = 0; l < c->L; ++l)
+        for (unsigned b = 64; b-- > 0;)
+            if (c->tabs[l].q >> b) { if (b + 1 > bits) bits = b + 1; break; }
+    while ((size_t{1} << lc) < chunk) ++lc;
+    if (2 * bits + lc > 128) return fail(PF_ERR_UNSUPPORTED, "pf_ct_pt_dot: chunk * q^2 must stay below 2^128 (lazy 128-bit sums)");
+    const size_t groups = (n_pt + chunk - 1) / chunk, blocks = groups * c->L * (c->N / 512);
+    if (blocks > 0x7fffffffull) return fail(PF_ERR_INVALID_ARG, "too many blocks for one launch");
+    PF_GUARD(c->device);
+    DotArgs a{c->d_limbs, ct_ntt, pt_ntt, out, c->L, c->logn, n_ct, n_pt, chunk};
+    hipLaunchKernelGGL(k_ct_pt_dot, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 pf_status pf_apply_galois_ct(pf_ctx *c, const uint64_t *ct_in, uint64_t *ct_out, uint64_t *target, size_t B, uint32_t galois_elt, pf_stream stream) {
     if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
     if (B == 0) return PF_OK;

@@ -118,7 +118,8 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
     bfv::Ciphertexts &one = w.one, &sel = w.sel;
     one.count = 1;
     if (one.data.words() < per) one.data = bfv::DeviceWords(dev, per);
-    if (w.prod.words() < S * per) w.prod = bfv::DeviceWords(dev, S * per);
+    const size_t prod_cts = S > C * 16 ? S : C * 16;                                   // the products of a column, or 16 partial sums per column
+    if (w.prod.words() < prod_cts * per) w.prod = bfv::DeviceWords(dev, prod_cts * per);
     bfv::DeviceWords &prod = w.prod;
     const bool trace = std::getenv("PF_PIR_TRACE") != nullptr;
     auto stamp = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
@@ -133,16 +134,35 @@ void answer(const bfv::Context &ctx, const Database &db, const bfv::Ciphertexts 
         check(pf_memcpy_d2d(dev, one.data.ptr(), query.data.ptr() + q * per, per * 8, nullptr), "d2d");
         expand(ctx, one, keys, lay.levels, sel, &w);
         stamp("expand", t0);
-        // per column: products in NTT form, summed there by halving (one launch per halving), one inverse transform at the end
-        for (size_t c = 0; c < C; ++c) {
-            const size_t cnt = P - c * S < S ? P - c * S : S;
-            check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt() + c * S * L * N, cnt, prod.ptr(), cnt, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
-            for (size_t n = cnt; n > 1;) {
-                const size_t half = n / 2, keep = n - half;                              // fold the last `half` onto the first `half`
-                check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
-                n = keep;
+        // per column: sum_k selection_k x database_k in NTT form, one inverse transform at the end
+        const size_t splits = 16;
+        if (S % splits == 0 && S >= 256) {
+            // the selection ciphertexts go to NTT form once; ONE pass over them and the database forms the sums, split 16 ways along
+            // k for parallelism (pf_ct_pt_dot: no product is ever written), and the 16 partial sums of a column are added up
+            const size_t chunk = S / splits, G = (P + chunk - 1) / chunk;
+            check(pf_ntt_forward(ctx.ring(), sel.data.ptr(), S * 2 * L, nullptr), "pf_ntt_forward");
+            check(pf_ct_pt_dot(ctx.ring(), sel.data.ptr(), S, db.ntt(), P, chunk, prod.ptr(), nullptr), "pf_ct_pt_dot");
+            for (size_t c = 0; c < C; ++c) {
+                uint64_t *part = prod.ptr() + c * splits * per;
+                for (size_t n = G - c * splits < splits ? G - c * splits : splits; n > 1;) {
+                    const size_t half = n / 2, keep = n - half;
+                    check(pf_poly_add(ctx.ring(), part, part + keep * per, part, half * 2 * L, nullptr), "pf_poly_add");
+                    n = keep;
+                }
+                check(pf_ntt_inverse_to(ctx.ring(), part, reply.data.ptr() + (q * C + c) * per, 2 * L, nullptr), "pf_ntt_inverse_to");
             }
-            check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), reply.data.ptr() + (q * C + c) * per, 2 * L, nullptr), "pf_ntt_inverse_to");
+        } else {
+            // small bases: products in NTT form, summed there by halving (one launch per halving)
+            for (size_t c = 0; c < C; ++c) {
+                const size_t cnt = P - c * S < S ? P - c * S : S;
+                check(pf_ct_pt_mul(ctx.ring(), sel.data.ptr(), db.ntt() + c * S * L * N, cnt, prod.ptr(), cnt, PF_CTPT_OUT_NTT, nullptr), "pf_ct_pt_mul");
+                for (size_t n = cnt; n > 1;) {
+                    const size_t half = n / 2, keep = n - half;                          // fold the last `half` onto the first `half`
+                    check(pf_poly_add(ctx.ring(), prod.ptr(), prod.ptr() + keep * per, prod.ptr(), half * 2 * L, nullptr), "pf_poly_add");
+                    n = keep;
+                }
+                check(pf_ntt_inverse_to(ctx.ring(), prod.ptr(), reply.data.ptr() + (q * C + c) * per, 2 * L, nullptr), "pf_ntt_inverse_to");
+            }
         }
         stamp("columns", t0);
     }

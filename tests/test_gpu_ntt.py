@@ -376,6 +376,30 @@ def test_mul_monomial(pf, N, qs):
         c.mul_monomial(d, 3, out=d)
 
 
+@pytest.mark.parametrize("N,qs", [(1024, oracle.BFV_DEFAULT[1024]), (8192, oracle.BFV_DEFAULT[8192][:4])])
+def test_ct_pt_dot(pf, N, qs):
+    """pf_ct_pt_dot against ct_pt_mul(IN_NTT | OUT_NTT) + additions through the oracle: groups of `chunk` plaintexts, the
+    ciphertexts reused cyclically, a ragged last group."""
+    rng = np.random.default_rng(N + 7)
+    L, n_ct, n_pt, chunk = len(qs), 6, 16, 3
+    ct = np.stack([np.stack([rng.integers(0, q, (2, N), dtype=np.uint64) for q in qs], axis=1) for _ in range(n_ct)])   # [n_ct,2,L,N]
+    ct[0, 0, 0, :5] = np.uint64(qs[0] - 1)
+    pt = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_pt)])                 # [n_pt,L,N]
+    pt[1, 0, :5] = np.uint64(qs[0] - 1)
+    c = _ctx(pf, N, qs)
+    o = oracle.Oracle(N, qs)
+    got = pf.to_host_u64(c.ct_pt_dot(pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev()), chunk))
+    assert got.shape == (6, 2, L, N)
+    for g in range(6):
+        acc = np.zeros((2, L, N), dtype=np.uint64)
+        for p_ in range(g * chunk, min((g + 1) * chunk, n_pt)):
+            for comp in range(2):
+                acc[comp] = o.addsub(acc[comp], o.dyadic_mul(ct[p_ % n_ct, comp], pt[p_]), o.ADD)
+        assert (got[g] == acc).all(), g
+    with pytest.raises(pf.PfError):
+        c.ct_pt_dot(pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev()), 4)      # 4 does not divide 6
+
+
 def test_out_of_place_transforms(pf):
     N, qs = 4096, oracle.BFV_DEFAULT[4096][:2]
     rng = np.random.default_rng(9)
