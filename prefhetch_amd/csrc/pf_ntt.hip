@@ -430,6 +430,7 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     // 15 x 16 digit transforms per ciphertext = 1.1 GB of workspace; 192 at N = 8192 with 4 + 1 moduli = 0.4 GB)
     size_t sub = 4096 / ((size_t)D * K) / 16 * 16;
     if (sub < 16) sub = 16;
+    if (const char *e = getenv("PF_KS_ROUND")) { const long v = atol(e); if (v > 0) sub = (size_t)v; }   // experiments: ciphertexts per round
     if (sub > B) sub = B;
     const size_t x_words = sub * D * K * N, acc_words = sub * 2 * K * N;
     const size_t need = (x_words + acc_words) * 8;
