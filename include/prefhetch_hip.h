@@ -130,7 +130,7 @@ pf_status pf_apply_galois_ct(pf_ctx *ctx, const uint64_t *ct_in, uint64_t *ct_ou
  *   ksk    [D][2][D+1][N]   digit I's key as SEAL stores it (PublicKey data: 2 polys x K limbs), NTT form
  *   ct     [B][2][D][N]     coefficient form, updated in place
  * RNS digit decomposition -> D*(D+1) forward NTTs -> 128-bit lazy multiply-accumulate with the key ->
- * inverse NTTs -> division by P with rounding.  Uses an internal workspace (~4096 digit transforms per round: 16 ciphertexts at config 5, 192 at N = 8192) that is
+ * inverse NTTs -> division by P with rounding.  Uses an internal workspace (4096-8192 digit transforms per round: 32 ciphertexts at config 5 = 2.2 GB, 192 at N = 8192 = 0.4 GB) that is
  * allocated on first use: call once outside graph capture. */
 pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
 

@@ -426,9 +426,10 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     PF_GUARD(c->device);
     hipStream_t s = as_stream(stream);
     const size_t N = c->N;
-    // ciphertexts per round of the workspace: a multiple of 16 with at most ~4096 digit transforms per launch (16 at config 5's
-    // 15 x 16 digit transforms per ciphertext = 1.1 GB of workspace; 192 at N = 8192 with 4 + 1 moduli = 0.4 GB)
-    size_t sub = 4096 / ((size_t)D * K) / 16 * 16;
+    // ciphertexts per round of the workspace: a multiple of 16 with at most ~4096 digit transforms per launch up to N = 16384
+    // (192 at N = 8192 with 4 + 1 moduli = 0.4 GB of workspace) and ~8192 at N = 32768 (32 at config 5's 15 x 16 digit transforms
+    // per ciphertext = 2.2 GB); both swept on MI355X (PF_KS_ROUND): 16 / 32 / 64 at config 5 = 23.7 / 23.0 / 23.0 ms per 256
+    size_t sub = (c->logn >= 15 ? 8192 : 4096) / ((size_t)D * K) / 16 * 16;
     if (sub < 16) sub = 16;
     if (const char *e = getenv("PF_KS_ROUND")) { const long v = atol(e); if (v > 0) sub = (size_t)v; }   // experiments: ciphertexts per round
     if (sub > B) sub = B;
