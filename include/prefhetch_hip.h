@@ -14,7 +14,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the device's null stream).  Calls enqueue work
  *     and return; nothing synchronises unless documented.  The polynomial calls (NTT, dyadic, add, ct x pt)
  *     and pf_flat_search after pf_flat_reserve never allocate, free or synchronise, so they can be
- *     captured into a hipGraph; pf_key_switch (first call) and pf_ivfpq_search_lists say what they do.
+ *     captured into a hipGraph; pf_key_switch (see pf_key_switch_reserve) and pf_ivfpq_search_lists say what they do.
  *   - RNS polynomial buffers: `n_limb_polys` polynomials of N uint64 coefficients, contiguous;
  *     polynomial p belongs to RNS limb (p % L).  A SEAL Ciphertext's data() -- size x L x N,
  *     poly-major, then limb, then coefficient -- and a batch of them therefore pass through unchanged.
@@ -130,9 +130,15 @@ pf_status pf_apply_galois_ct(pf_ctx *ctx, const uint64_t *ct_in, uint64_t *ct_ou
  *   ksk    [D][2][D+1][N]   digit I's key as SEAL stores it (PublicKey data: 2 polys x K limbs), NTT form
  *   ct     [B][2][D][N]     coefficient form, updated in place
  * RNS digit decomposition -> D*(D+1) forward NTTs -> 128-bit lazy multiply-accumulate with the key ->
- * inverse NTTs -> division by P with rounding.  Uses an internal workspace (4096-8192 digit transforms per round: 32 ciphertexts at config 5 = 2.2 GB, 192 at N = 8192 = 0.4 GB) that is
- * allocated on first use: call once outside graph capture. */
+ * inverse NTTs -> division by P with rounding.  Uses an internal workspace (4096-8192 digit transforms per round: 32 ciphertexts at config 5 = 2.2 GB, 192 at N = 8192 = 0.4 GB).
+ * After pf_key_switch_reserve(ctx, B') with B' >= B the call neither allocates nor synchronises nor reads the environment (it can be
+ * captured into a hipGraph); without it the workspace is grown on first use.
+ * At N = 32768 with every modulus below 2^56 (SEAL's defaults: config 5) the digit transforms run as two passes with the key products
+ * accumulated in registers inside the second (prefhetch_amd/csrc/ks_split.hpp). */
 pf_status pf_key_switch(pf_ctx *ctx, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream);
+
+/* Allocates the key-switching workspace for calls of up to B polynomials (may free and re-allocate: not inside graph capture). */
+pf_status pf_key_switch_reserve(pf_ctx *ctx, size_t B);
 
 /* Same, with every input ciphertext multiplied by `fanout` consecutive plaintexts: out[b] = ct[b / fanout] x pt[b],
  * b < B; ct holds ceil(B / fanout) ciphertexts, pt_ntt B plaintexts, out B ciphertexts (must not alias ct when

@@ -15,7 +15,7 @@ SYMBOLS = [
     "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_memcpy_d2d", "pf_stream_synchronize",
     "pf_ctx_create", "pf_ctx_destroy", "pf_ctx_info", "pf_ctx_force_u64",
     "pf_ntt_forward", "pf_ntt_inverse", "pf_ntt_forward_to", "pf_ntt_inverse_to", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
-    "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_apply_galois_ct", "pf_poly_mul_monomial", "pf_poly_addsub_monomial", "pf_key_switch", "pf_pack_rows", "pf_pack_rows_ntt", "pf_ct_rows_mul", "pf_ct_pt_dot",
+    "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_apply_galois_ct", "pf_poly_mul_monomial", "pf_poly_addsub_monomial", "pf_key_switch", "pf_key_switch_reserve", "pf_pack_rows", "pf_pack_rows_ntt", "pf_ct_rows_mul", "pf_ct_pt_dot",
     "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
     "pf_flat_reserve", "pf_flat_search_packed", "pf_flat_exact16",
     "pf_multi_create", "pf_multi_destroy", "pf_multi_info", "pf_multi_ring", "pf_multi_flat", "pf_multi_reserve", "pf_multi_member",
@@ -61,6 +61,7 @@ def _load():
     lib.pf_poly_negate.argtypes = [vp, vp, vp, sz, vp]
     lib.pf_ct_pt_mul.argtypes = [vp, vp, vp, sz, vp, sz, i32, vp]
     lib.pf_key_switch.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.pf_key_switch_reserve.argtypes = [vp, sz]
     lib.pf_pack_rows.argtypes = [vp, vp, vp, sz, u32, vp, vp]
     lib.pf_apply_galois.argtypes = [vp, vp, vp, sz, u32, vp]
     lib.pf_apply_galois_ct.argtypes = [vp, vp, vp, vp, sz, u32, vp]

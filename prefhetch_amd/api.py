@@ -241,6 +241,10 @@ class RnsContext:
         check(lib.pf_ct_rows_mul(self._h, pc, flat._h, pi, B, rows, int(fanout), po, _stream(self.device)), "pf_ct_rows_mul")
         return out
 
+    def key_switch_reserve(self, B):
+        """Allocates the key-switching workspace for calls of up to B polynomials, so that key_switch_ never allocates."""
+        check(lib.pf_key_switch_reserve(self._h, int(B)), "pf_key_switch_reserve")
+
     def key_switch_(self, target, ksk, ct):
         """This context holds the key moduli (special prime last).  target [B,D,N], ksk [D,2,D+1,N] (NTT form),
         ct [B,2,D,N]: the switched polynomial is added into ct in place."""

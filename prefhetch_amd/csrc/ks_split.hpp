@@ -1,0 +1,269 @@
+// ks_split.hpp -- key switching at N = 32768 as a two-kernel split of the digit transforms (round 3).
+//
+// SEAL's Evaluator::switch_key_inplace (linked un-vendored by /root/reference/CMakeLists.txt:33-38,66; restated in
+// oracle/pf_oracle.c: pfo_key_switch) needs, per switched polynomial, D x K forward transforms of 32768 points (config 5:
+// 15 x 16 = 240), each multiplied into two 128-bit accumulators.  The single-kernel transform (ntt_core.hpp) gives a whole CU
+// to one workgroup at this degree (128 KiB of LDS, every register): its load, pass, exchange and store phases run one after
+// the other (VALU ~ 50 % busy) and the finished transforms travel through memory twice more for the multiply-accumulate.
+// Here the 15 stages are cut after the seventh:
+//
+//   pass A (body_ksA)  index = r * 256 + c.  A workgroup of 512 threads takes a tile of all 128 rows r x 64 adjacent columns c
+//                      of ONE (digit, key modulus) transform and runs stages 0..6 (index bits 14..8) on it: four stages in
+//                      registers (thread = one (r mod 8, c), registers = r div 8), one exchange through LDS, three more
+//                      (wave = two values of r div 8, lane = c, registers = r mod 8).  Every twiddle of pass A is wave-uniform:
+//                      scalar loads, scalar operands.  The tile goes back to memory lazily reduced (values < 2^62).
+//   pass B (body_ksB)  a wave takes two of the 128 contiguous 256-point blocks (one per half-wave: 32 lanes x 8 coefficients)
+//                      of ONE (ciphertext, key modulus) and loops over the D digits: load the block of pass A's output,
+//                      finish stages 7..14 (3 + 3 + 2 stages in registers, two wave-private transposes through LDS, no
+//                      workgroup barrier anywhere), multiply by the two key components on the same 8 consecutive
+//                      coefficients and add into 128-bit accumulators that stay in registers; after the loop ONE Barrett
+//                      reduction and one store per component.  Finished digit transforms never exist in memory.
+//
+// Arithmetic: the lazy 64-bit family only (ArithU64L: every modulus below 2^56).  A digit is a residue of ANOTHER modulus
+// below 2^56; the lazy forward butterflies take it as it is (x' = x + m, y' = x + 4q - m with 0 <= m < 4q for ANY y < 2^64:
+// after 15 stages a value is below 2^56 + 60 q < 2^62), so neither the reduction modulo m_J on load nor the canonical
+// form after the last stage is needed: the 128-bit sums take 15 x 2^62 x 2^56 < 2^122.
+//
+// Like ntt_core.hpp the file compiles for the device and, unchanged, for the host (tests/cpp/sim_ntt.cpp: one OS thread per
+// lane), which checks the index maps against the oracle without a GPU.
+#pragma once
+#include "ntt_core.hpp"
+
+namespace pf {
+
+struct KsGeo {
+    static constexpr int LOGN = 15, N = 1 << LOGN;
+    static constexpr int A_T = 512, A_R = 16, A_COLS = 64, A_TILES = 256 / A_COLS;      // pass A: 128 rows x 64 columns per workgroup
+    static constexpr int A_LDS = 128 * A_COLS;                                            // u64 entries
+    static constexpr int B_T = 256, B_R = 8, B_CHUNK = 2048, B_CHUNKS = N / B_CHUNK;     // pass B: 8 blocks of 256 per workgroup
+    static constexpr int B_LDS_WAVE = 2 * 320;                                            // u64 entries per wave (two padded blocks)
+    static constexpr int B_LDS = (B_T / 64) * B_LDS_WAVE;
+};
+
+// One forward stage over NR registers: butterfly b pairs registers k0 (bit KB clear) and k0 | 2^KB, its twiddle is twf(b >> KB).
+template <int NR, int KB, bool UTW, class A, class TwFn>
+PF_HD void ks_fwd_stage(typename A::V (&r)[NR], const A &ar, TwFn &&twf) {
+    using V = typename A::V;
+    static_for<0, NR / 2, 4>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
+        V ys[4], xs[4], yo[4];
+        typename A::TwR ts[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            ys[i] = r[k0 | (1 << KB)];
+            ts[i] = twf(b >> KB);
+        }
+        ar.template mul_tw_n<4, UTW>(ys, ts);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            xs[i] = r[k0];
+        }
+        ar.template fwd_combine_n<4>(xs, yo, ys);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            r[k0] = xs[i]; r[k0 | (1 << KB)] = yo[i];
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pass A: stages 0..6 of one (digit, modulus) transform on the tile of columns [64 cb, 64 cb + 64).
+//   src  the digit polynomial (coefficient form, residues of ITS modulus: any value below 2^56)
+//   dst  this transform's slot of the intermediate buffer, natural index order
+// `sync` is the workgroup barrier.
+// ------------------------------------------------------------------------------------------------------------------
+template <class A, class Sync>
+PF_HD void body_ksA(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, int cb,
+                    uint64_t *lds, int tid, Sync &&sync) {
+    static_assert(std::is_same<typename A::V, uint64_t>::value, "the split key switch runs the 64-bit lazy family");
+    const int lane = tid & 63, w = wave_uniform(tid >> 6);
+    uint64_t r[16];
+    // registers = r div 8 (index bits 14..11), wave = r mod 8, lane = column
+    const uint64_t *s0 = src + (size_t)w * 256 + cb * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = s0[(size_t)k * 2048];
+    // stages 0..3: the twiddle of stage s, group g is table entry 2^s + g -- workgroup-uniform
+    ks_fwd_stage<16, 3, true>(r, ar, [&](int g) { return const_load_tw(tw + 1 + g); });
+    ks_fwd_stage<16, 2, true>(r, ar, [&](int g) { return const_load_tw(tw + 2 + g); });
+    ks_fwd_stage<16, 1, true>(r, ar, [&](int g) { return const_load_tw(tw + 4 + g); });
+    ks_fwd_stage<16, 0, true>(r, ar, [&](int g) { return const_load_tw(tw + 8 + g); });
+    // exchange: LDS position of (row, column) is row * 64 + column; lanes stay columns on both sides
+    uint64_t *l0 = lds + w * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) l0[k * 512] = r[k];
+    sync();
+    // registers = (g, r mod 8) with r div 8 = 2 w + g
+    const uint64_t *l1 = lds + w * 1024 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = l1[k * 64];
+    // stages 4..6 (index bits 10..8 = register bits 2..0): entry 2^s + ((r div 8) << (s - 4)) + (r mod 8 >> (7 - s)); with
+    // b the butterfly number over the 16 registers that is 2^s + (2 w << (s - 4)) + (b >> KB): wave-uniform
+    const TwU64 *t4 = tw + 16 + 2 * w, *t5 = tw + 32 + 4 * w, *t6 = tw + 64 + 8 * w;
+    ks_fwd_stage<16, 2, true>(r, ar, [&](int g) { return const_load_tw(t4 + g); });
+    ks_fwd_stage<16, 1, true>(r, ar, [&](int g) { return const_load_tw(t5 + g); });
+    ks_fwd_stage<16, 0, true>(r, ar, [&](int g) { return const_load_tw(t6 + g); });
+    uint64_t *d0 = dst + (size_t)w * 4096 + cb * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d0[(size_t)k * 256] = r[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pass B.  Per half-wave (32 lanes, lane l) one 256-point block; c = index inside the block, bits i7..i0.
+//   R1: registers (i7 i6 i0), lanes (i5 i4 i3 i2 i1)          stages 7, 8      (memory: 16 bytes per lane, 512 per half-wave)
+//   R2: registers (i5 i4 i3), lanes (i7 i6 i0 | i2 i1)        stages 9, 10, 11
+//   R3: registers (i2 i1 i0), lanes (i7 i6 i5 i4 i3)          stages 12, 13, 14 (a lane owns 8 consecutive coefficients)
+// LDS positions (u64 entries inside the half-wave's 320-entry area): exchange 1 uses c + 8 (c >> 6), exchange 2 uses
+// c + 2 (c >> 3) -- both free of bank conflicts on their narrow side (ds_read_b64 over the 32 lanes of R2; ds_write_b64 of R2
+// and the 80-byte lane pitch of R3's 16-byte reads).  LDS operations of one wave execute in order; `wsync` keeps the
+// compiler (device) or the other lanes' threads (host) in step.
+// ------------------------------------------------------------------------------------------------------------------
+PF_HD constexpr int ksb_p1(int c) { return c + 8 * (c >> 6); }
+PF_HD constexpr int ksb_p2(int c) { return c + 2 * (c >> 3); }
+
+// 128-bit lazy multiply-accumulate (lo, hi) += x * k
+PF_HD void ks_mac128(uint64_t &lo, uint64_t &hi, uint64_t x, uint64_t k) {
+    const uint64_t pl = x * k, ph = mulhi64(x, k);
+    const uint64_t s = lo + pl;
+    hi += ph + (s < pl ? 1 : 0);
+    lo = s;
+}
+
+// The 17 per-lane twiddles of stages 7..14 of one block: they depend on (modulus, block, lane) only -- not on the digit nor on the
+// ciphertext -- so pass B fetches them once and keeps them in registers (68 VGPRs) for its whole digit loop.
+struct KsbTw {
+    TwU64 s7, s8[2];                 // R1
+    TwU64 s9, s10[2], s11[4];        // R2
+    TwU64 s12, s13[2], s14[4];       // R3
+    PF_HD void load(const TwU64 *__restrict__ tw, int blk, int l) {
+        s7 = tw[128 + blk]; s8[0] = tw[256 + 2 * blk]; s8[1] = tw[257 + 2 * blk];
+        // stage 7 + u, u = 2, 3, 4: entry 2^(7+u) + ((4 blk + (i7 i6)) << (u - 2)) + group, (i7 i6) = l >> 3 in R2
+        const int e2 = 4 * blk + (l >> 3);
+        s9 = tw[512 + e2]; s10[0] = tw[1024 + 2 * e2]; s10[1] = tw[1025 + 2 * e2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s11[g] = tw[2048 + 4 * e2 + g];
+        // stage 7 + u, u = 5, 6, 7: entry 2^(7+u) + ((32 blk + l) << (u - 5)) + group
+        const int e3 = 32 * blk + l;
+        s12 = tw[4096 + e3]; s13[0] = tw[8192 + 2 * e3]; s13[1] = tw[8193 + 2 * e3];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s14[g] = tw[16384 + 4 * e3 + g];
+    }
+};
+
+// Stages 7..14 of one block, in place in r (R1 order in, R3 order out).  l = lane & 31, area = this half-wave's LDS area.
+template <class A, class WSync>
+PF_HD void ksb_finish_fwd(uint64_t (&r)[8], const A &ar, const KsbTw &T, int l, uint64_t *area, WSync &&wsync) {
+    // R1: stage 7 (register bit 2 = i7), stage 8 (register bit 1 = i6; group = i7)
+    ks_fwd_stage<8, 2, false>(r, ar, [&](int) { return T.s7; });
+    ks_fwd_stage<8, 1, false>(r, ar, [&](int g) { return T.s8[g]; });
+    // exchange 1: write registers (k2 k1 | k0) at c = 128 k2 + 64 k1 + 2 l + k0, 16 bytes per store
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        *reinterpret_cast<U64x2 *>(area + ksb_p1(128 * (kk >> 1) + 64 * (kk & 1)) + 2 * l) = U64x2{r[2 * kk], r[2 * kk + 1]};
+    wsync();
+    // R2: lane = (i7 i6 i0 | i2 i1), register k = (i5 i4 i3): c = 128 l4 + 64 l3 + 8 k + 2 (l & 3) + l2
+    const int hi2 = l >> 3;                                          // (i7 i6)
+    {
+        const uint64_t *rd = area + ksb_p1(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = rd[8 * k];
+    }
+    ks_fwd_stage<8, 2, false>(r, ar, [&](int) { return T.s9; });
+    ks_fwd_stage<8, 1, false>(r, ar, [&](int g) { return T.s10[g]; });
+    ks_fwd_stage<8, 0, false>(r, ar, [&](int g) { return T.s11[g]; });
+    wsync();                                                         // every lane has read exchange 1 out
+    // exchange 2: write register k at the same c, positions c + 2 (c >> 3)
+    {
+        uint64_t *wr = area + ksb_p2(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[10 * k] = r[k];
+    }
+    wsync();
+    // R3: lane l owns c = 8 l + k
+    {
+        const U64x2 *rd = reinterpret_cast<const U64x2 *>(area + 10 * l);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const U64x2 v = rd[j]; r[2 * j] = v.x; r[2 * j + 1] = v.y; }
+    }
+    ks_fwd_stage<8, 2, false>(r, ar, [&](int) { return T.s12; });
+    ks_fwd_stage<8, 1, false>(r, ar, [&](int g) { return T.s13[g]; });
+    ks_fwd_stage<8, 0, false>(r, ar, [&](int g) { return T.s14[g]; });
+    wsync();                                                         // exchange 2 read out before the next digit's exchange 1
+}
+
+// x        pass A's output for (this ciphertext, digit 0, this modulus); digit I sits at x + I * x_stride
+// ksk      key for (digit 0, component 0, this modulus): component c of digit I at ksk + (2 I + c) * k_stride
+// out0/1   accumulated products of the two components for (this ciphertext, this modulus), NTT form, canonical
+// chunk    which 2048 coefficients (0..15) this workgroup covers
+template <class A, class WSync>
+PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *__restrict__ x, size_t x_stride,
+                    const uint64_t *__restrict__ ksk, size_t k_stride, uint64_t *__restrict__ out0, uint64_t *__restrict__ out1, int D, int chunk,
+                    uint64_t *lds, int tid, WSync &&wsync) {
+    static_assert(std::is_same<typename A::V, uint64_t>::value, "the split key switch runs the 64-bit lazy family");
+    const int lane = tid & 63, wv = tid >> 6, h = lane >> 5, l = lane & 31;
+    const int blk = chunk * 8 + wv * 2 + h;
+    uint64_t *area = lds + wv * KsGeo::B_LDS_WAVE + h * 320;
+    const size_t base = (size_t)blk * 256;
+    uint64_t lo[2][8], hi[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[c][e] = hi[c][e] = 0;
+    KsbTw T;
+    T.load(tw, blk, l);
+    // the block of digit I + 1 is requested while digit I is worked on (16 registers); the key of digit I at the top of its
+    // iteration -- it is only needed after the eight stages
+    const uint64_t *xi = x + base + 2 * l;
+    U64x2 xn[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) xn[kk] = *reinterpret_cast<const U64x2 *>(xi + 128 * (kk >> 1) + 64 * (kk & 1));
+    for (int I = 0; I < D; ++I) {
+        uint64_t r[8];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { r[2 * kk] = xn[kk].x; r[2 * kk + 1] = xn[kk].y; }
+        U64x2 kv[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const U64x2 *kp = reinterpret_cast<const U64x2 *>(ksk + (size_t)(2 * I + c) * k_stride + base + 8 * l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kv[c][j] = kp[j];
+        }
+        {
+            const uint64_t *xnext = xi + (size_t)(I + 1 < D ? I + 1 : I) * x_stride;      // last digit: a harmless re-read
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xn[kk] = *reinterpret_cast<const U64x2 *>(xnext + 128 * (kk >> 1) + 64 * (kk & 1));
+        }
+        PF_SCHED_FENCE();
+        ksb_finish_fwd(r, ar, T, l, area, wsync);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ks_mac128(lo[c][2 * j], hi[c][2 * j], r[2 * j], kv[c][j].x);
+                ks_mac128(lo[c][2 * j + 1], hi[c][2 * j + 1], r[2 * j + 1], kv[c][j].y);
+            }
+    }
+    // one Barrett reduction per sum; stores staged through the half-wave's area so that every store instruction covers 512
+    // contiguous bytes (a lane owns 64 consecutive bytes: stored directly that is a 64-byte lane stride, 0.93 against 3.27 TB/s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t v0 = ar.barrett128(lo[c][2 * j], hi[c][2 * j]), v1 = ar.barrett128(lo[c][2 * j + 1], hi[c][2 * j + 1]);
+            wr[j] = U64x2{v0 >= ar.q ? v0 - ar.q : v0, v1 >= ar.q ? v1 - ar.q : v1};
+        }
+        wsync();
+        uint64_t *o = (c ? out1 : out0) + base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = 2 * (32 * j + l);                          // coefficient pair number 32 j + l
+            *reinterpret_cast<U64x2 *>(o + cc) = *reinterpret_cast<const U64x2 *>(area + ksb_p2(cc));
+        }
+        wsync();
+    }
+}
+
+}  // namespace pf

@@ -1,0 +1,21 @@
+// pf_ks_split.hpp -- launch interface of the two-pass key switch at N = 32768 (kernels: pf_ks_split.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pf_ntt_kernels.hpp"
+
+namespace pf {
+
+struct KsSplitArgs {
+    const LimbDev *limbs;
+    const void *tables;
+    const uint64_t *target;      // [nb][D][N] digits of this round's ciphertexts (coefficient form)
+    uint64_t *x;                 // [nb][D][nJ][N] pass A's output
+    const uint64_t *ksk;         // [D][2][K][N] key, NTT form
+    uint64_t *acc;               // [nb][2][K][N] accumulated products, NTT form (columns J0 .. J0 + nJ - 1 written)
+    uint32_t D, K, nb, J0, nJ;
+};
+
+void launch_ksA(const KsSplitArgs &a, hipStream_t s);
+void launch_ksB(const KsSplitArgs &a, hipStream_t s);
+
+}  // namespace pf

@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include "pf_ks_kernels.hpp"
+#include "pf_ks_split.hpp"
 #include "pf_ntt_kernels.hpp"
 #include "pf_common.hpp"
 #include "tables.hpp"
@@ -29,8 +30,27 @@ struct pf_ctx {
     std::vector<LimbTables> tabs;
     LimbDev *d_limbs = nullptr;
     void *d_tables = nullptr;       // all twiddle tables, one allocation
-    void *ks_ws = nullptr;          // key-switching workspace (digit NTTs + products), grown on demand
+    void *ks_ws = nullptr;          // key-switching workspace (digit NTTs + products): pf_key_switch_reserve, else grown on demand
     size_t ks_ws_bytes = 0;
+    // tuning, read ONCE when the context is created (PF_KS_ROUND, PF_KS_JROUND, PF_KS_SPLIT; experiments only):
+    size_t ks_round = 0;            // ciphertexts per round of the workspace (0: the default for this ring)
+    uint32_t ks_jround = 0;         // two-pass path: key moduli per round (0: all)
+    int ks_split = 1;               // N = 32768, lazy 64-bit family: the two-pass digit transforms of ks_split.hpp
+    bool split_ok() const { return logn == 15 && arith() == 2 && ks_split; }
+    size_t round_size(size_t B) const {
+        const uint32_t K = L, D = K - 1;
+        // ciphertexts per round: a multiple of 16 with at most ~4096 digit transforms per launch up to N = 16384 (192 at N = 8192 with
+        // 4 + 1 moduli = 0.4 GB of workspace) and ~8192 at N = 32768 (32 at config 5's 15 x 16 digit transforms = 2.2 GB)
+        size_t sub = (logn >= 15 ? 8192 : 4096) / ((size_t)D * K) / 16 * 16;
+        if (sub < 16) sub = 16;
+        if (ks_round) sub = ks_round;
+        return sub > B ? B : sub;
+    }
+    uint32_t jround() const { return (split_ok() && ks_jround && ks_jround < L) ? ks_jround : L; }
+    size_t ws_bytes(size_t B) const {
+        const size_t sub = round_size(B), K = L, D = K - 1;
+        return (sub * D * jround() * N + sub * 2 * K * N) * 8;
+    }
 };
 
 namespace {
@@ -167,6 +187,9 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
     PF_GUARD(device);
     pf_ctx *c = new pf_ctx;
     c->device = device; c->N = N; c->L = L; c->logn = logn;
+    if (const char *e = getenv("PF_KS_ROUND")) { const long v = atol(e); if (v > 0) c->ks_round = (size_t)v; }
+    if (const char *e = getenv("PF_KS_JROUND")) { const long v = atol(e); if (v > 0) c->ks_jround = (uint32_t)v; }
+    if (const char *e = getenv("PF_KS_SPLIT")) c->ks_split = atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
@@ -416,6 +439,26 @@ pf_status pf_apply_galois_ct(pf_ctx *c, const uint64_t *ct_in, uint64_t *ct_out,
     return PF_OK;
 }
 
+namespace {
+pf_status ks_workspace(pf_ctx *c, size_t B) {
+    const size_t need = c->ws_bytes(B);
+    if (need > c->ks_ws_bytes) {
+        if (c->ks_ws) { PF_HIP(hipFree(c->ks_ws)); c->ks_ws = nullptr; c->ks_ws_bytes = 0; }
+        PF_HIP(hipMalloc(&c->ks_ws, need));
+        c->ks_ws_bytes = need;
+    }
+    return PF_OK;
+}
+}  // namespace
+
+pf_status pf_key_switch_reserve(pf_ctx *c, size_t B) {
+    if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
+    if (c->L < 2) return fail(PF_ERR_INVALID_ARG, "key switching needs a context with the key moduli: data primes then the special prime");
+    if (B == 0) return PF_OK;
+    PF_GUARD(c->device);
+    return ks_workspace(c, B);
+}
+
 pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, uint64_t *ct, size_t B, pf_stream stream) {
     if (!c) return fail(PF_ERR_INVALID_ARG, "null context");
     if (B == 0) return PF_OK;
@@ -426,41 +469,44 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
     PF_GUARD(c->device);
     hipStream_t s = as_stream(stream);
     const size_t N = c->N;
-    // ciphertexts per round of the workspace: a multiple of 16 with at most ~4096 digit transforms per launch up to N = 16384
-    // (192 at N = 8192 with 4 + 1 moduli = 0.4 GB of workspace) and ~8192 at N = 32768 (32 at config 5's 15 x 16 digit transforms
-    // per ciphertext = 2.2 GB); both swept on MI355X (PF_KS_ROUND): 16 / 32 / 64 at config 5 = 23.7 / 23.0 / 23.0 ms per 256
-    size_t sub = (c->logn >= 15 ? 8192 : 4096) / ((size_t)D * K) / 16 * 16;
-    if (sub < 16) sub = 16;
-    if (const char *e = getenv("PF_KS_ROUND")) { const long v = atol(e); if (v > 0) sub = (size_t)v; }   // experiments: ciphertexts per round
-    if (sub > B) sub = B;
-    const size_t x_words = sub * D * K * N, acc_words = sub * 2 * K * N;
-    const size_t need = (x_words + acc_words) * 8;
-    if (need > c->ks_ws_bytes) {
-        if (c->ks_ws) { PF_HIP(hipFree(c->ks_ws)); c->ks_ws = nullptr; c->ks_ws_bytes = 0; }
-        PF_HIP(hipMalloc(&c->ks_ws, need));
-        c->ks_ws_bytes = need;
+    const size_t sub = c->round_size(B);
+    {   // no allocation on this path once pf_key_switch_reserve(ctx, B) has run (then the call can be captured into a hipGraph)
+        const pf_status st = ks_workspace(c, B);
+        if (st != PF_OK) return st;
     }
+    const bool split = c->split_ok();
+    const uint32_t nJ = c->jround();
+    const size_t x_words = sub * D * nJ * N;
     uint64_t *x = static_cast<uint64_t *>(c->ks_ws), *acc = x + x_words;
     const int arith = c->arith();
     const uint32_t chunk_log = c->logn < 11 ? c->logn : 11;
     const size_t chunks = N >> chunk_log;
     for (size_t b0 = 0; b0 < B; b0 += sub) {
         const size_t nb = B - b0 < sub ? B - b0 : sub;
-        // 1. digit NTTs: x[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)
-        NttArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, nullptr, nb * D * K, K, 0, D};
-        size_t ks_grid = nb * D * K;
-        if (c->logn >= 15 && PF_KS_PERSIST) {               // persistent workgroups, one per CU, a multiple of K of them (k_ks_ntt)
-            const size_t per = ((size_t)c->num_cus / K) * K;
-            if (per && per < ks_grid) ks_grid = per;
-        }
-        pf_status st = dispatch_logn(c, arith, 3, 0, a, ks_grid, s);
-        if (st != PF_OK) return st;
-        // 2. multiply-accumulate with the key
         KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn, (uint32_t)nb};
-        hipLaunchKernelGGL(k_ks_mac, dim3((unsigned)((K * chunks + 7) / 8 * 8 * nb)), dim3(256), 0, s, k);
+        if (split) {
+            // 1 + 2. digit transforms in two passes, the second one accumulating the key products (ks_split.hpp)
+            for (uint32_t J0 = 0; J0 < K; J0 += nJ) {
+                KsSplitArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, ksk, acc, D, K, (uint32_t)nb, J0, K - J0 < nJ ? K - J0 : nJ};
+                launch_ksA(a, s);
+                launch_ksB(a, s);
+            }
+        } else {
+            // 1. digit NTTs: x[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)
+            NttArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, nullptr, nb * D * K, K, 0, D};
+            size_t ks_grid = nb * D * K;
+            if (c->logn >= 15 && PF_KS_PERSIST) {               // persistent workgroups, one per CU, a multiple of K of them (k_ks_ntt)
+                const size_t per = ((size_t)c->num_cus / K) * K;
+                if (per && per < ks_grid) ks_grid = per;
+            }
+            pf_status st = dispatch_logn(c, arith, 3, 0, a, ks_grid, s);
+            if (st != PF_OK) return st;
+            // 2. multiply-accumulate with the key
+            hipLaunchKernelGGL(k_ks_mac, dim3((unsigned)((K * chunks + 7) / 8 * 8 * nb)), dim3(256), 0, s, k);
+        }
         // 3. back to coefficient form, all K limbs of both components
         NttArgs ai{c->d_limbs, c->d_tables, acc, acc, nullptr, 0, K, 0, 0};
-        st = dispatch_logn(c, arith, 1, 0, ai, nb * 2 * K, s);
+        pf_status st = dispatch_logn(c, arith, 1, 0, ai, nb * 2 * K, s);
         if (st != PF_OK) return st;
         // 4. divide by the special prime with rounding and add into the ciphertext
         hipLaunchKernelGGL(k_ks_moddown, dim3((unsigned)(nb * 2 * D * chunks)), dim3(256), 0, s, k);

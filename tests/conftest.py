@@ -23,7 +23,7 @@ def _build_sim(name, extra):
     import ctypes as C
     so = os.path.join(ROOT, "tests", "cpp", name)
     src = os.path.join(ROOT, "tests", "cpp", "sim_ntt.cpp")
-    deps = [src] + [os.path.join(ROOT, "prefhetch_amd", "csrc", f) for f in ("ntt_core.hpp", "tables.hpp", "lds_swizzle_tab.hpp")]
+    deps = [src] + [os.path.join(ROOT, "prefhetch_amd", "csrc", f) for f in ("ntt_core.hpp", "tables.hpp", "lds_swizzle_tab.hpp", "ks_split.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-std=c++20", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-DPF_RANGE_CHECK", "-shared", "-fPIC"] + extra + [src, "-o", so])
     lib = C.CDLL(so)

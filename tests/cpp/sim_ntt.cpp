@@ -82,3 +82,51 @@ extern "C" uint64_t pf_sim_psi(int logn, uint64_t q) {
     LimbTables t; std::string err;
     return build_limb_tables(1u << logn, q, t, err) ? t.psi : 0;
 }
+
+// ---- the two-pass key switch at N = 32768 (prefhetch_amd/csrc/ks_split.hpp): pass A over every (digit, modulus) transform,
+// pass B over every (modulus, chunk), one OS thread per lane.  moduli[K], target [D][N], ksk [D][2][K][N] -> acc [2][K][N]
+// (NTT form, canonical): what k_ksA + k_ksB compute for one ciphertext.
+#include "../../prefhetch_amd/csrc/ks_split.hpp"
+
+extern "C" int pf_sim_ks_split(int D, int K, const uint64_t *moduli, const uint64_t *target, const uint64_t *ksk, uint64_t *acc) {
+    constexpr size_t N = KsGeo::N;
+    std::vector<LimbTables> tabs(K);
+    std::string err;
+    for (int j = 0; j < K; ++j) {
+        if (!u64_lazy_ok(moduli[j], 15)) return -3;
+        if (!build_limb_tables((uint32_t)N, moduli[j], tabs[j], err)) return -2;
+    }
+    std::vector<uint64_t> x((size_t)D * K * N);
+    for (int I = 0; I < D; ++I)
+        for (int J = 0; J < K; ++J) {
+            const ArithU64L ar{moduli[J], 2 * moduli[J], tabs[J].ratio0, tabs[J].ratio1};
+            for (int cb = 0; cb < KsGeo::A_TILES; ++cb) {
+                std::vector<uint64_t> lds(KsGeo::A_LDS);
+                std::barrier bar(KsGeo::A_T);
+                std::vector<std::thread> th;
+                for (int tid = 0; tid < KsGeo::A_T; ++tid)
+                    th.emplace_back([&, tid] {
+                        auto sync = [&] { bar.arrive_and_wait(); };
+                        body_ksA<ArithU64L>(ar, tabs[J].fwd_u.data(), target + (size_t)I * N, x.data() + ((size_t)I * K + J) * N, cb, lds.data(), tid, sync);
+                    });
+                for (auto &t : th) t.join();
+            }
+        }
+    for (int J = 0; J < K; ++J) {
+        const ArithU64L ar{moduli[J], 2 * moduli[J], tabs[J].ratio0, tabs[J].ratio1};
+        for (int chunk = 0; chunk < KsGeo::B_CHUNKS; ++chunk) {
+            std::vector<uint64_t> lds(KsGeo::B_LDS + 2);
+            uint64_t *l16 = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
+            std::barrier bar(KsGeo::B_T);            // a barrier over the whole workgroup is a (stronger) wave barrier
+            std::vector<std::thread> th;
+            for (int tid = 0; tid < KsGeo::B_T; ++tid)
+                th.emplace_back([&, tid] {
+                    auto wsync = [&] { bar.arrive_and_wait(); };
+                    body_ksB<ArithU64L>(ar, tabs[J].fwd_u.data(), x.data() + (size_t)J * N, (size_t)K * N, ksk + (size_t)J * N, (size_t)K * N,
+                                        acc + (size_t)J * N, acc + ((size_t)K + J) * N, D, chunk, l16, tid, wsync);
+                });
+            for (auto &t : th) t.join();
+        }
+    }
+    return 0;
+}
