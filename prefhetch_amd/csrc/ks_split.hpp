@@ -123,13 +123,55 @@ PF_HD void body_ksA(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *_
 PF_HD constexpr int ksb_p1(int c) { return c + 8 * (c >> 6); }
 PF_HD constexpr int ksb_p2(int c) { return c + 2 * (c >> 3); }
 
-// 128-bit lazy multiply-accumulate (lo, hi) += x * k
-PF_HD void ks_mac128(uint64_t &lo, uint64_t &hi, uint64_t x, uint64_t k) {
-    const uint64_t pl = x * k, ph = mulhi64(x, k);
-    const uint64_t s = lo + pl;
-    hi += ph + (s < pl ? 1 : 0);
-    lo = s;
+// 128-bit lazy multiply-accumulate, four at a time: (hi_i : lo_i) += x_i * k_i with x_i < 2^62, k_i < 2^56 and sums below 2^128
+// (the caller's bound: at most 63 terms).  hipcc expands the C form (x * k, mulhi64, compare, add) into 24 instructions per
+// term, most of them moves into the aligned register pairs that 64-bit multiplies want.  Here, per term, with x = x1:x0, k = k1:k0:
+//     M  = x1 k0 + x0 k1                 2 v_mad_u64_u32; below 2^63, no carry
+//     lo = x0 k0 + lo                    1 v_mad_u64_u32, carry-out cA (weight 2^64)
+//     hi = x1 k1 + hi                    1 v_mad_u64_u32 (sums stay below 2^128: hi never wraps)
+//     lo.high += M.low                   1 v_add_co_u32,  carry-out c1 (weight 2^64)
+//     t  = M.high + c1 + cA              2 v_addc_co_u32 (M.high < 2^31: no wrap)
+//     hi = t * 1 + hi                    1 v_mad_u64_u32
+// 8 instructions.  The halves of a pair are named by 32-bit operands of a second asm statement (the compiler keeps them in place, as
+// in mulsub4_lo64); the four terms are interleaved so that no carry is read within two states of its write.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_MC_M0(i) "v_mad_u64_u32 %[M" #i "], %[cy], %[x" #i "1], %[k" #i "0], 0\n\t"
+#define PF_MC_M1(i) "v_mad_u64_u32 %[M" #i "], %[cy], %[x" #i "0], %[k" #i "1], %[M" #i "]\n\t"
+#define PF_MC_LO(i) "v_mad_u64_u32 %[lo" #i "], %[cA" #i "], %[x" #i "0], %[k" #i "0], %[lo" #i "]\n\t"
+#define PF_MC_HI(i) "v_mad_u64_u32 %[hi" #i "], %[cy], %[x" #i "1], %[k" #i "1], %[hi" #i "]\n\t"
+#define PF_MC_OUT1(i) [M##i] "=&v"(M[i]), [lo##i] "+v"(lo[i]), [hi##i] "+v"(hi[i]), [cA##i] "=&s"(cA[i])
+#define PF_MC_IN1(i) [x##i##0] "v"((uint32_t)x[i]), [x##i##1] "v"((uint32_t)(x[i] >> 32)), [k##i##0] "v"((uint32_t)k[i]), [k##i##1] "v"((uint32_t)(k[i] >> 32))
+#define PF_MC_A1(i) "v_add_co_u32 %[a" #i "], %[c" #i "], %[a" #i "], %[ml" #i "]\n\t"
+#define PF_MC_T0(i) "v_addc_co_u32 %[t" #i "], %[c" #i "], %[mh" #i "], 0, %[c" #i "]\n\t"
+#define PF_MC_T1(i) "v_addc_co_u32 %[t" #i "], %[cA" #i "], %[t" #i "], 0, %[cA" #i "]\n\t"
+#define PF_MC_H2(i) "v_mad_u64_u32 %[hi" #i "], %[cy], %[t" #i "], 1, %[hi" #i "]\n\t"
+#define PF_MC_OUT2(i) [a##i] "+v"(a1[i]), [t##i] "=&v"(t[i]), [hi##i] "+v"(hi[i]), [c##i] "=&s"(c1[i]), [cA##i] "+s"(cA[i])
+#define PF_MC_IN2(i) [ml##i] "v"((uint32_t)M[i]), [mh##i] "v"((uint32_t)(M[i] >> 32))
+PF_HD void ks_mac128x4(uint64_t (&lo)[4], uint64_t (&hi)[4], const uint64_t (&x)[4], const uint64_t (&k)[4]) {
+    uint64_t M[4], cA[4], c1[4], cy;
+    asm(PF_MS_ALL(PF_MC_M0) PF_MS_ALL(PF_MC_M1) PF_MS_ALL(PF_MC_LO) PF_MS_ALL(PF_MC_HI)
+        : PF_MC_OUT1(0), PF_MC_OUT1(1), PF_MC_OUT1(2), PF_MC_OUT1(3), [cy] "=&s"(cy)
+        : PF_MC_IN1(0), PF_MC_IN1(1), PF_MC_IN1(2), PF_MC_IN1(3));
+    uint32_t a1[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = (uint32_t)(lo[i] >> 32);
+    asm(PF_MS_ALL(PF_MC_A1) PF_MS_ALL(PF_MC_T0) PF_MS_ALL(PF_MC_T1) PF_MS_ALL(PF_MC_H2)
+        : PF_MC_OUT2(0), PF_MC_OUT2(1), PF_MC_OUT2(2), PF_MC_OUT2(3), [cy] "=&s"(cy)
+        : PF_MC_IN2(0), PF_MC_IN2(1), PF_MC_IN2(2), PF_MC_IN2(3));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = ((uint64_t)a1[i] << 32) | (uint32_t)lo[i];
+    asm("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));              // keeps the pairs whole (see mulsub4_lo64)
 }
+#else
+PF_HD void ks_mac128x4(uint64_t (&lo)[4], uint64_t (&hi)[4], const uint64_t (&x)[4], const uint64_t (&k)[4]) {
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t pl = x[i] * k[i], ph = mulhi64(x[i], k[i]);
+        const uint64_t s = lo[i] + pl;
+        hi[i] += ph + (s < pl ? 1 : 0);
+        lo[i] = s;
+    }
+}
+#endif
 
 // The 17 per-lane twiddles of stages 7..14 of one block: they depend on (modulus, block, lane) only -- not on the digit nor on the
 // ciphertext -- so pass B fetches them once and keeps them in registers (68 VGPRs) for its whole digit loop.
@@ -153,8 +195,10 @@ struct KsbTw {
 };
 
 // Stages 7..14 of one block, in place in r (R1 order in, R3 order out).  l = lane & 31, area = this half-wave's LDS area.
-template <class A, class WSync>
-PF_HD void ksb_finish_fwd(uint64_t (&r)[8], const A &ar, const KsbTw &T, int l, uint64_t *area, WSync &&wsync) {
+// `mid` runs between the second exchange and the last three stages (the caller requests the key there: late enough to keep 32
+// registers free during the first five stages, early enough for the L2 round trip to hide under the last three).
+template <class A, class WSync, class Mid>
+PF_HD void ksb_finish_fwd(uint64_t (&r)[8], const A &ar, const KsbTw &T, int l, uint64_t *area, WSync &&wsync, Mid &&mid) {
     // R1: stage 7 (register bit 2 = i7), stage 8 (register bit 1 = i6; group = i7)
     ks_fwd_stage<8, 2, false>(r, ar, [&](int) { return T.s7; });
     ks_fwd_stage<8, 1, false>(r, ar, [&](int g) { return T.s8[g]; });
@@ -187,6 +231,7 @@ PF_HD void ksb_finish_fwd(uint64_t (&r)[8], const A &ar, const KsbTw &T, int l, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const U64x2 v = rd[j]; r[2 * j] = v.x; r[2 * j + 1] = v.y; }
     }
+    mid();
     ks_fwd_stage<8, 2, false>(r, ar, [&](int) { return T.s12; });
     ks_fwd_stage<8, 1, false>(r, ar, [&](int g) { return T.s13[g]; });
     ks_fwd_stage<8, 0, false>(r, ar, [&](int g) { return T.s14[g]; });
@@ -215,34 +260,46 @@ PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *_
     T.load(tw, blk, l);
     // the block of digit I + 1 is requested while digit I is worked on (16 registers); the key of digit I at the top of its
     // iteration -- it is only needed after the eight stages
-    const uint64_t *xi = x + base + 2 * l;
+    // addresses = a workgroup-uniform base (scalar registers) + a 32-bit per-lane byte offset: no 64-bit address pairs held per lane
+    const uint32_t xoff = (uint32_t)(base + 2 * l) * 8u, koff = (uint32_t)(base + 8 * l) * 8u;
+    auto ld16 = [](const uint64_t *ubase, uint32_t byte_off) {
+        return *reinterpret_cast<const U64x2 *>(reinterpret_cast<const char *>(ubase) + byte_off);
+    };
     U64x2 xn[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xn[kk] = *reinterpret_cast<const U64x2 *>(xi + 128 * (kk >> 1) + 64 * (kk & 1));
+    for (int kk = 0; kk < 4; ++kk) xn[kk] = ld16(x, xoff + 8u * (128 * (kk >> 1) + 64 * (kk & 1)));
     for (int I = 0; I < D; ++I) {
         uint64_t r[8];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { r[2 * kk] = xn[kk].x; r[2 * kk + 1] = xn[kk].y; }
-        U64x2 kv[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const U64x2 *kp = reinterpret_cast<const U64x2 *>(ksk + (size_t)(2 * I + c) * k_stride + base + 8 * l);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kv[c][j] = kp[j];
-        }
         {
-            const uint64_t *xnext = xi + (size_t)(I + 1 < D ? I + 1 : I) * x_stride;      // last digit: a harmless re-read
+            const uint64_t *xnext = x + (size_t)(I + 1 < D ? I + 1 : I) * x_stride;      // last digit: a harmless re-read
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xn[kk] = *reinterpret_cast<const U64x2 *>(xnext + 128 * (kk >> 1) + 64 * (kk & 1));
+            for (int kk = 0; kk < 4; ++kk) xn[kk] = ld16(xnext, xoff + 8u * (128 * (kk >> 1) + 64 * (kk & 1)));
         }
         PF_SCHED_FENCE();
-        ksb_finish_fwd(r, ar, T, l, area, wsync);
+        U64x2 kv[2][4];
+        ksb_finish_fwd(r, ar, T, l, area, wsync, [&] {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint64_t *kp = ksk + (size_t)(2 * I + c) * k_stride;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kv[c][j] = ld16(kp, koff + 16u * j);
+            }
+            PF_SCHED_FENCE();
+        });
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ks_mac128(lo[c][2 * j], hi[c][2 * j], r[2 * j], kv[c][j].x);
-                ks_mac128(lo[c][2 * j + 1], hi[c][2 * j + 1], r[2 * j + 1], kv[c][j].y);
+            for (int g = 0; g < 2; ++g) {                            // coefficients 4 g .. 4 g + 3 of this lane
+                uint64_t l4[4], h4[4];
+                const uint64_t x4[4] = {r[4 * g], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3]};
+                const uint64_t k4[4] = {kv[c][2 * g].x, kv[c][2 * g].y, kv[c][2 * g + 1].x, kv[c][2 * g + 1].y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l4[e] = lo[c][4 * g + e]; h4[e] = hi[c][4 * g + e]; }
+                ks_mac128x4(l4, h4, x4, k4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[c][4 * g + e] = l4[e]; hi[c][4 * g + e] = h4[e]; }
             }
     }
     // one Barrett reduction per sum; stores staged through the half-wave's area so that every store instruction covers 512
