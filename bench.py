@@ -64,7 +64,7 @@ def self_launch(args):
     not touched the GPU (no HIP call has happened yet: torch is imported, nothing else), one rank per GPU, rendezvous on
     127.0.0.1.  Never an exec of this process."""
     rehearsal = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1"
-    have = torch.cuda.device_count()                     # counts devices without initialising the runtime
+    have = torch.cuda.device_count()                     # the ranks are fresh CHILD processes either way (nothing is exec'd from here)
     if not rehearsal and have < args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but this machine shows {have} HIP device(s) "
                  "(PF_BENCH_SINGLE_DEVICE=1 PF_BENCH_BACKEND=gloo rehearses the control flow on one GPU)")
@@ -204,6 +204,93 @@ def roofline_block(B, ms_b, sustained_ms=None):
     return r
 
 
+
+CFG2_MODULI = [0xFFFFEE001, 0xFFFFC4001]                                   # SEAL BFVDefault(4096) data primes
+CFG5_MODULI = [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0x7FFFFFFFBD0001, 0x7FFFFFFFBA0001, 0x7FFFFFFFAA0001, 0x7FFFFFFFA50001,
+               0x7FFFFFFF9F0001, 0x7FFFFFFF7E0001, 0x7FFFFFFF770001, 0x7FFFFFFF380001, 0x7FFFFFFF330001, 0x7FFFFFFF2D0001,
+               0x7FFFFFFF170001, 0x7FFFFFFF150001, 0x7FFFFFFEF00001, 0xFFFFFFFFF70001]   # BFVDefault(32768): 15 data primes + special
+
+
+def _timed(fn, reps):
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def _rand_residues(shape_of, moduli, axis, gen, dev):
+    """uniform residues per limb, generated on the device (int64 holds every modulus below 2^63)"""
+    return torch.stack([torch.randint(0, q, shape_of, generator=gen, device=dev, dtype=torch.int64) for q in moduli], dim=axis).contiguous()
+
+
+def config2_block(pf, dev):
+    """BASELINE config 2: N=4096, 2 limbs, batch 256 fused ct x pt (extra figure, outside the timed region)."""
+    import oracle
+    N, qs, B = 4096, CFG2_MODULI, 256
+    g = torch.Generator(device=dev).manual_seed(20250801 + 2)
+    ctx = pf.RnsContext(N, qs, dev)
+    ct = _rand_residues((B, 2, N), qs, 2, g, dev)
+    pt = _rand_residues((B, N), qs, 1, g, dev)
+    out = torch.empty_like(ct)
+    ms = _timed(lambda: ctx.ct_pt_mul(ct, pt, out=out), 50)
+    alg = 40 * len(qs) * N * B
+    exp = oracle.Oracle(N, qs).ct_pt_mul(pf.to_host_u64(ct[:2]), pf.to_host_u64(pt[:2]))
+    return {"workload": "N=4096, 2 limbs, batch 256 fused ct x pt", "ct_x_pt_ms": ms, "queries_per_s": B / (ms * 1e-3),
+            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+            "first_2_bit_exact_vs_oracle": bool((pf.to_host_u64(out[:2]) == exp).all()),
+            "note": "50 back-to-back launches; one launch of 1024 workgroups fills the chip 1.3 times: launch-bound shape"}
+
+
+def config5_block(pf, dev):
+    """BASELINE config 5: N=32768, 15 data primes + special prime, batch 256: forward / inverse NTT, fused ct x pt, and the
+    key switch of one polynomial per ciphertext (extra figures, outside the timed region).  Rows 0, 17, 255 against the oracle."""
+    import oracle
+    N, KQ, B = 32768, CFG5_MODULI, 256
+    DQ, D, K = KQ[:-1], len(KQ) - 1, len(KQ)
+    g = torch.Generator(device=dev).manual_seed(20250801 + 5)
+    ctx = pf.RnsContext(N, DQ, dev)
+    ct = _rand_residues((B, 2, N), DQ, 2, g, dev)                      # [B][2][15][N]: 2.0 GB
+    pt = _rand_residues((B, N), DQ, 1, g, dev)                         # [B][15][N]
+    out = torch.empty_like(ct)
+    rows = [0, 17, 255]
+    o = oracle.Oracle(N, DQ)
+    ms_ctpt = _timed(lambda: ctx.ct_pt_mul(ct, pt, out=out), 5)
+    h_ct, h_pt = pf.to_host_u64(ct[rows]), pf.to_host_u64(pt[rows])
+    ok_ctpt = bool((pf.to_host_u64(out[rows]) == o.ct_pt_mul(h_ct, h_pt)).all())
+    ms_fwd = _timed(lambda: ctx.ntt_forward(ct, out=out), 5)
+    ok_fwd = bool((pf.to_host_u64(out[rows]) == o.ntt_forward(h_ct)).all())
+    ms_inv = _timed(lambda: ctx.ntt_inverse(out, out=out), 5)
+    n_polys = B * 2 * D
+    del pt, out
+    # key switching: the context holds the key moduli (special prime last); one polynomial per ciphertext is switched
+    ctxk = pf.RnsContext(N, KQ, dev)
+    ctxk.key_switch_reserve(B)
+    target = _rand_residues((B, N), DQ, 1, g, dev)                     # [B][15][N]
+    ksk = torch.stack([torch.stack([_rand_residues((N,), KQ, 0, g, dev) for _ in range(2)]) for _ in range(D)]).contiguous()   # [15][2][16][N]
+    h_t, h_c, h_k = pf.to_host_u64(target[rows]), pf.to_host_u64(ct[rows]), pf.to_host_u64(ksk)
+    work = ct.clone()
+    ctxk.key_switch_(target, ksk, work)
+    ok_ks = bool((pf.to_host_u64(work[rows]) == oracle.Oracle(N, KQ).key_switch(h_t, h_k, h_c)).all())
+    ms_ks = _timed(lambda: ctxk.key_switch_(target, ksk, work), 3)
+    # SURVEY 8(d): per switched polynomial read the digits (15 N 8) + write both components (2 15 N 8), read-modify-write counted
+    # once each way; the key (126 MB) once per batch
+    ks_bytes = B * (D * N * 8 + 2 * 2 * D * N * 8) + D * 2 * K * N * 8
+    return {"workload": "N=32768, 15 data primes + special prime, batch 256",
+            "forward_ntt_ms": ms_fwd, "forward_frac": 16 * N * n_polys / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "inverse_ntt_ms": ms_inv, "inverse_frac": 16 * N * n_polys / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ct_x_pt_ms": ms_ctpt, "ct_x_pt_frac": 40 * D * N * B / (ms_ctpt * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "key_switch_ms_per_256": ms_ks, "key_switch_us_per_polynomial": 1e3 * ms_ks / B,
+            "key_switch_digit_transforms": B * D * K, "key_switch_ns_per_digit_transform": 1e6 * ms_ks / (B * D * K),
+            "key_switch_algorithmic_bytes": ks_bytes, "key_switch_frac_of_hbm_peak": ks_bytes / (ms_ks * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "key_switch_bound": "valu (61 440 transforms of 32768 points in 64-bit modular arithmetic per batch; PMC: profiles/r03_pmc_keyswitch.txt)",
+            "verified_rows_vs_oracle": rows,
+            "verified": {"ct_x_pt": ok_ctpt, "forward_ntt": ok_fwd, "key_switch": ok_ks}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,7 +337,7 @@ def main():
     ctx = pf.RnsContext(N_RING, MODULI, dev)
     flat = pf.FlatL2(xb, dev)
     flat.reserve(B, TOPK)
-    exact16_active = flat.exact16() and B > 64
+    exact16_active = flat.operands16() == 2            # the bf16 tiles run for every batch size once the base passed the exactness check
     del xb
     # with a process group: the selection kernel writes this rank's packed block IN PLACE into `gathered`, then ONE all-gather
     gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if dist else None
@@ -412,6 +499,12 @@ def main():
         xq_g = torch.randn((B, DIM), generator=gg, device=dev)
         variants["gaussian_k200_ms"] = timed_search(flat_g, xq_g, TOPK)          # bf16 tiles as a conservative filter + fp32 chain on the survivors
         variants["gaussian_k100_ms"] = timed_search(flat_g, xq_g, 100)
+        def gauss_step():
+            flat_g.search(xq_g, TOPK)
+            ctx.ct_pt_mul(ct, pt, out=out)
+        ms_gstep = _timed(gauss_step, 10)
+        variants["gaussian_step_ms"] = ms_gstep
+        variants["value_gaussian"] = B / (ms_gstep * 1e-3)          # the step with an N(0,1) base and queries (bf16 tiles as a filter + fp32 survivors)
         if flat_g.operands16() == 1:
             Dg, Ig = flat_g.search(xq_g, TOPK)
             flat_g.operands16(0)
@@ -474,6 +567,15 @@ def main():
         del res_two
         del ids, ptb, ctn, res
 
+    cfg2 = cfg5 = None
+    if extras:
+        cfg2 = config2_block(pf, dev)
+        try:
+            cfg5 = config5_block(pf, dev)
+        except Exception as ex:                                    # never lose the headline line to an extra
+            cfg5 = {"error": repr(ex)}
+        torch.cuda.empty_cache()
+
     ms_a = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_b = float(np.mean([(e[4].elapsed_time(e[5]) if args.overlap else e[1].elapsed_time(e[2])) for e in ev]))
     ms_c = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
@@ -515,6 +617,15 @@ def main():
                 {"kernel": "k_l2_tile (+ k_select), whole stage", "bound": "mfma", "achieved": tf, "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                  "frac": tf / F32_MATRIX_PEAK_TF, "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b, "operands": "fp32"}),
         }
+        if dist:
+            res["collective_ranks"] = dist.get_world_size()       # the world size the all-gather actually ran with
+            res["collective_backend"] = backend
+        if variants and "value_gaussian" in variants:
+            res["value_gaussian"] = variants["value_gaussian"]
+        if cfg2:
+            res["config2"] = cfg2
+        if cfg5:
+            res["config5"] = cfg5
         if pipelined:
             res["two_batches_in_flight"] = pipelined
         if variants:
