@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 
@@ -122,37 +123,81 @@ HttpListener::~HttpListener() { if (m_Fd >= 0) ::close(m_Fd); }
 
 void HttpListener::stop() { m_Stop = true; }
 
+namespace {
+
+// Parses ONE complete message out of the front of `buf` without touching the socket.  NeedMore: the head or the body is not all
+// there yet (`head_done` then says whether the head is: the caller answers "Expect: 100-continue" at that point).
+enum class Parse { Ok, NeedMore, Bad, TooLarge };
+Parse try_parse(std::string &buf, Message &m, size_t max_body, bool &head_done) {
+    head_done = false;
+    const size_t end = buf.find("\r\n\r\n");
+    if (end == std::string::npos) return buf.size() > (1u << 20) ? Parse::Bad : Parse::NeedMore;
+    const std::string head = buf.substr(0, end);
+    size_t pos = head.find("\r\n");
+    m.start = head.substr(0, pos);
+    m.headers.clear();
+    while (pos != std::string::npos) {
+        const size_t next = head.find("\r\n", pos + 2);
+        const std::string line = head.substr(pos + 2, next == std::string::npos ? std::string::npos : next - pos - 2);
+        const size_t colon = line.find(':');
+        if (colon == std::string::npos) { if (!line.empty()) return Parse::Bad; }
+        else {
+            size_t v = colon + 1;
+            while (v < line.size() && (line[v] == ' ' || line[v] == '\t')) ++v;
+            m.headers.emplace_back(lower(line.substr(0, colon)), line.substr(v));
+        }
+        pos = next;
+    }
+    size_t len = 0;
+    if (const std::string *cl = header(m, "content-length")) {
+        if (cl->empty() || cl->find_first_not_of("0123456789") != std::string::npos || cl->size() > 18) return Parse::Bad;
+        len = (size_t)std::stoull(*cl);
+    } else if (header(m, "transfer-encoding")) return Parse::Bad;            // chunked bodies: not spoken here
+    if (len > max_body) return Parse::TooLarge;
+    head_done = true;
+    if (buf.size() < end + 4 + len) return Parse::NeedMore;
+    m.body = buf.substr(end + 4, len);
+    buf.erase(0, end + 4 + len);
+    return Parse::Ok;
+}
+
+}  // namespace
+
+// One thread, many connections: the listening socket and every open client socket sit in ONE poll set, bytes are taken off a
+// socket only when poll says they are there (never a blocking recv), and a request is handled -- one at a time, like the
+// reference, which never calls setThreadNum -- as soon as all of it is buffered.  A client that stalls in the middle of a request is
+// answered 408 and closed after REQUEST_TIMEOUT_MS, an idle keep-alive connection is closed after IDLE_TIMEOUT_MS; neither keeps
+// any other client waiting, and stop() is seen within one poll interval whatever the clients do.
 size_t HttpListener::serve(size_t max_requests) {
+    using Clock = std::chrono::steady_clock;
+    constexpr int POLL_MS = 100, REQUEST_TIMEOUT_MS = 10000, IDLE_TIMEOUT_MS = 30000;
+    constexpr size_t MAX_CONNECTIONS = 256;
+    struct Conn { int fd; std::string buf; Clock::time_point last; bool continued = false; bool eof = false; };
+    std::vector<Conn> conns;
     size_t served = 0;
-    while (!m_Stop && (max_requests == 0 || served < max_requests)) {
-        pollfd pfd{m_Fd, POLLIN, 0};
-        const int pr = ::poll(&pfd, 1, 100);                         // wakes up to look at the stop flag
-        if (pr <= 0) continue;
-        const int c = ::accept(m_Fd, nullptr, nullptr);
-        if (c < 0) continue;
-        int one = 1;
-        ::setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-        std::string buf;
+    auto close_at = [&](size_t i) { ::close(conns[i].fd); conns.erase(conns.begin() + (long)i); };
+    // answers every complete request at the front of the connection's buffer; false = close the connection
+    auto drain = [&](Conn &c) -> bool {
         while (!m_Stop && (max_requests == 0 || served < max_requests)) {
-            pollfd cp{c, POLLIN, 0};
-            if (buf.empty()) {                                       // idle keep-alive connection: do not block the listener for ever
-                const int r = ::poll(&cp, 1, 100);
-                if (r == 0) { if (m_Stop) break; continue; }
-                if (r < 0) break;
-            }
             Message m;
-            const Recv rc = read_message(c, buf, m, m_MaxBody, [c](const Message &head) {
-                const std::string *e = header(head, "expect");
-                if (e && lower(*e) == "100-continue") send_all(c, "HTTP/1.1 100 Continue\r\n\r\n", 25);
-            });
-            if (rc == Recv::Closed) break;
-            if (rc == Recv::TooLarge) { respond(c, 413, "Payload Too Large", "{\"error\":\"body too large\"}", false); break; }
-            if (rc == Recv::Bad) { respond(c, 400, "Bad Request", "{\"error\":\"malformed request\"}", false); break; }
+            bool head_done = false;
+            const Parse rc = try_parse(c.buf, m, m_MaxBody, head_done);
+            if (rc == Parse::NeedMore) {
+                if (head_done && !c.continued) {
+                    const std::string *e = header(m, "expect");
+                    if (e && lower(*e) == "100-continue") send_all(c.fd, "HTTP/1.1 100 Continue\r\n\r\n", 25);
+                    c.continued = true;
+                }
+                return true;
+            }
+            c.continued = false;
+            if (rc == Parse::TooLarge) { respond(c.fd, 413, "Payload Too Large", "{\"error\":\"body too large\"}", false); return false; }
+            if (rc == Parse::Bad) { respond(c.fd, 400, "Bad Request", "{\"error\":\"malformed request\"}", false); return false; }
             // request line: METHOD SP target SP HTTP/1.x
             const size_t s1 = m.start.find(' '), s2 = m.start.rfind(' ');
             if (s1 == std::string::npos || s2 == s1 || m.start.compare(s2 + 1, 7, "HTTP/1.") != 0) {
-                respond(c, 400, "Bad Request", "{\"error\":\"malformed request line\"}", false);
-                break;
+                respond(c.fd, 400, "Bad Request", "{\"error\":\"malformed request line\"}", false);
+                return false;
             }
             const std::string method = m.start.substr(0, s1);
             std::string target = m.start.substr(s1 + 1, s2 - s1 - 1);
@@ -161,22 +206,61 @@ size_t HttpListener::serve(size_t max_requests) {
             const std::string *conn = header(m, "connection");
             const bool keep = !(conn && lower(*conn) == "close") && m.start.compare(s2 + 1, 8, "HTTP/1.0") != 0;
             ++served;
-            if (method != "GET" && method != "POST") { respond(c, 405, "Method Not Allowed", "{\"error\":\"GET or POST\"}", keep); continue; }
+            if (method != "GET" && method != "POST") { respond(c.fd, 405, "Method Not Allowed", "{\"error\":\"GET or POST\"}", keep); if (!keep) return false; continue; }
             const std::string route = target.empty() || target[0] != '/' ? target : target.substr(1);
             try {
-                respond(c, 200, "OK", m_Handler(method, route, m.body), keep);
+                respond(c.fd, 200, "OK", m_Handler(method, route, m.body), keep);
             } catch (const std::out_of_range &e) {
                 // wire::handle signals an unknown route this way; a missing JSON key inside a known route is the
                 // client's malformed body -- Drogon would answer 500 for the escaping exception either way
                 const bool unknown = std::string(e.what()).rfind("no such route", 0) == 0;
-                respond(c, unknown ? 404 : 500, unknown ? "Not Found" : "Internal Server Error", std::string("{\"error\":\"") + (unknown ? "unknown route" : "bad request body") + "\"}", keep);
+                respond(c.fd, unknown ? 404 : 500, unknown ? "Not Found" : "Internal Server Error", std::string("{\"error\":\"") + (unknown ? "unknown route" : "bad request body") + "\"}", keep);
             } catch (const std::exception &) {
-                respond(c, 500, "Internal Server Error", "{\"error\":\"handler failed\"}", keep);
+                respond(c.fd, 500, "Internal Server Error", "{\"error\":\"handler failed\"}", keep);
             }
-            if (!keep) break;
+            c.last = Clock::now();
+            if (!keep) return false;
         }
-        ::close(c);
+        return true;
+    };
+    while (!m_Stop && (max_requests == 0 || served < max_requests)) {
+        std::vector<pollfd> set(1 + conns.size());
+        set[0] = pollfd{m_Fd, (short)(conns.size() < MAX_CONNECTIONS ? POLLIN : 0), 0};
+        for (size_t i = 0; i < conns.size(); ++i) set[1 + i] = pollfd{conns[i].fd, POLLIN, 0};
+        const int pr = ::poll(set.data(), (nfds_t)set.size(), POLL_MS);     // wakes up to look at the stop flag and the timeouts
+        if (pr < 0 && errno != EINTR) break;
+        const auto now = Clock::now();
+        for (size_t i = conns.size(); i-- > 0;) {                            // backwards: close_at() erases
+            Conn &c = conns[i];
+            const short ev = pr > 0 ? set[1 + i].revents : 0;
+            bool alive = true;
+            if (ev & POLLIN) {
+                char tmp[65536];
+                const ssize_t r = ::recv(c.fd, tmp, sizeof tmp, MSG_DONTWAIT);
+                if (r > 0) { c.buf.append(tmp, (size_t)r); c.last = now; alive = drain(c); }
+                else if (r == 0) alive = false;                              // the peer closed; a partial request dies with it
+                else if (errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR) alive = false;
+            } else if (ev & (POLLERR | POLLHUP | POLLNVAL)) {
+                alive = false;
+            }
+            if (alive) {
+                const auto quiet = std::chrono::duration_cast<std::chrono::milliseconds>(now - c.last).count();
+                if (!c.buf.empty() && quiet > REQUEST_TIMEOUT_MS) { respond(c.fd, 408, "Request Timeout", "{\"error\":\"request not completed in time\"}", false); alive = false; }
+                else if (c.buf.empty() && quiet > IDLE_TIMEOUT_MS) alive = false;
+            }
+            if (!alive) close_at(i);
+            if (m_Stop || (max_requests && served >= max_requests)) break;
+        }
+        if (pr > 0 && (set[0].revents & POLLIN) && !m_Stop) {
+            const int c = ::accept(m_Fd, nullptr, nullptr);
+            if (c >= 0) {
+                int one = 1;
+                ::setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                conns.push_back(Conn{c, std::string(), Clock::now()});
+            }
+        }
     }
+    for (const Conn &c : conns) ::close(c.fd);
     return served;
 }
 

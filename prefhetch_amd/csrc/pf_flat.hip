@@ -1562,6 +1562,10 @@ struct pf_flat {
     size_t ws_bytes = 0;
     size_t wg_slots = 1024;   // workgroups of the tile kernel resident on the device at once (CUs x occupancy)
     size_t num_cus = 256;
+    // tuning knobs, read from the environment ONCE when the index is created (experiments; never on the search path)
+    size_t b16_min_nq = 1;    // PF_FLAT_B16_MIN_NQ: smallest batch that takes the bf16 tiles
+    size_t group_cap = 64;    // PF_FLAT_GROUP_CAP: most column tiles one workgroup of k_l2_tile16 walks
+    double growth_div = 0.0;  // PF_FLAT_GROWTH_DIV: survivors per chunk as a fraction of the candidate capacity (0: the defaults)
 };
 
 namespace {
@@ -1635,6 +1639,9 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     PF_GUARD(device);
     pf_flat *f = new pf_flat;
     f->device = device; f->nb = nb; f->d = d;
+    if (const char *v = getenv("PF_FLAT_B16_MIN_NQ")) f->b16_min_nq = (size_t)atoi(v);
+    if (const char *v = getenv("PF_FLAT_GROUP_CAP")) { if (atoi(v) > 0) f->group_cap = (size_t)atoi(v); }
+    if (const char *v = getenv("PF_FLAT_GROWTH_DIV")) f->growth_div = atof(v);
     const size_t bytes = (nb ? nb : 1) * (size_t)d * 4;
     hipError_t e = hipMalloc((void **)&f->xb, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&f->bn, (nb ? nb : 1) * 4);
@@ -1734,8 +1741,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     float *slab = reinterpret_cast<float *>(base + w.off_slab);
     // Any batch size: for a few queries the 128-row tiles are mostly padding, but the scan is then bound by the bytes of the
     // base it streams, and the bf16 image is half the fp32 matrix (1 query over 1M x 128: 0.22 -> 0.16 ms, 64 queries 0.36 -> 0.23)
-    static const size_t b16_min_nq = getenv("PF_FLAT_B16_MIN_NQ") ? (size_t)atoi(getenv("PF_FLAT_B16_MIN_NQ")) : 1;   // experiments
-    const bool b16 = f->xb16 && f->use16 && nq >= b16_min_nq;
+    const bool b16 = f->xb16 && f->use16 && nq >= f->b16_min_nq;
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
     if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
@@ -1762,7 +1768,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             // round that is a quarter full takes as long as a full one.  (Before: two rounds whatever the chunk and walks of at most 8
             // tiles; 16 k columns ran as 2 x 1 tile, 213 k as 3.25 rounds of 8.  Measured over the cap: 8 0.555, 16 0.537, 32 0.520,
             // 64 0.514, 128 0.510 ms per search -- most chunks are then one round of workgroups that walk their whole share.)
-            static const size_t group_cap = getenv("PF_FLAT_GROUP_CAP") ? (size_t)atoi(getenv("PF_FLAT_GROUP_CAP")) : 64;   // experiments
+            const size_t group_cap = f->group_cap;
             const size_t per_round = 2 * f->num_cus / t.n_qtiles ? 2 * f->num_cus / t.n_qtiles : 1;       // column groups of one round
             const size_t rounds = (nct + per_round * group_cap - 1) / (per_round * group_cap);
             size_t group = (nct + per_round * rounds - 1) / (per_round * rounds);
@@ -1809,7 +1815,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     launch_select();
     // streaming chunks: sized so that the expected survivors per query, k * chunk / rows_seen, stay at a fraction 1/div of
     // the candidate capacity
-    static const double growth_div = getenv("PF_FLAT_GROWTH_DIV") ? atof(getenv("PF_FLAT_GROWTH_DIV")) : 0.0;   // experiments
+    const double growth_div = f->growth_div;
     size_t pos = boot;
     // Batches: rows_seen may grow by at most g_max = 1 + cap / (div * k) per chunk.  Taking g_max every time ends in a short
     // last chunk that still costs a launch and a merge; instead the number of chunks n is the smallest that g_max allows and

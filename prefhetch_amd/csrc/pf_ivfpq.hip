@@ -149,6 +149,7 @@ struct pf_ivfpq {
     int64_t *pin_probe = nullptr;
     uint64_t *pin_outoff = nullptr;
     hipEvent_t staged = nullptr;
+    hipEvent_t scanned = nullptr;     // end of the last call's scan kernel: the next call's stream waits for it before it overwrites d_probe / d_outoff
     size_t stage_cap = 0;
 };
 
@@ -193,6 +194,7 @@ pf_status pf_ivfpq_destroy(pf_ivfpq *h) {
         if (h->pin_probe) (void)hipHostFree(h->pin_probe);
         if (h->pin_outoff) (void)hipHostFree(h->pin_outoff);
         if (h->staged) (void)hipEventDestroy(h->staged);
+        if (h->scanned) (void)hipEventDestroy(h->scanned);
     }
     delete h;
     return PF_OK;
@@ -268,6 +270,7 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *h, const float *xq, const int64_t *pro
     const size_t need = nq * nprobe;
     if (need > h->stage_cap) {
         if (h->staged) PF_HIP(hipEventSynchronize(h->staged));
+        if (h->scanned) PF_HIP(hipEventSynchronize(h->scanned));      // the last scan still reads the buffers freed below
         if (h->d_probe) PF_HIP(hipFree(h->d_probe));
         if (h->d_outoff) PF_HIP(hipFree(h->d_outoff));
         if (h->pin_probe) PF_HIP(hipHostFree(h->pin_probe));
@@ -295,12 +298,17 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *h, const float *xq, const int64_t *pro
     }
     if (total > capacity) return fail(PF_ERR_INVALID_ARG, "output capacity too small for the probed lists");
     hipStream_t s = as_stream(stream);
+    // the DEVICE staging buffers are read by the previous call's scan kernel, possibly on another stream: this call's stream
+    // waits for that kernel (a device-side wait, the host does not block) before the copies overwrite them
+    if (h->scanned) PF_HIP(hipStreamWaitEvent(s, h->scanned, 0));
+    else PF_HIP(hipEventCreateWithFlags(&h->scanned, hipEventDisableTiming));
     PF_HIP(hipMemcpyAsync(h->d_probe, h->pin_probe, need * 8, hipMemcpyHostToDevice, s));
     PF_HIP(hipMemcpyAsync(h->d_outoff, h->pin_outoff, need * 8, hipMemcpyHostToDevice, s));
     PF_HIP(hipEventRecord(h->staged, s));
     ScanArgs a{xq, h->centroids, h->codebooks, h->d_codes, h->d_ids, h->d_off, h->d_probe, h->d_outoff, D, I, h->d, h->M, h->dsub, nprobe, h->nlist};
     hipLaunchKernelGGL(k_ivfpq_scan, dim3((unsigned)need), dim3(256), h->M * KSUB * 4, s, a);
     PF_HIP(hipGetLastError());
+    PF_HIP(hipEventRecord(h->scanned, s));
     return PF_OK;
 }
 

@@ -70,6 +70,9 @@ struct Member {
     int rank = 0, device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_done = nullptr;                        // peer-copy exchange: own pushes done
+    hipEvent_t ev_free = nullptr;                        // peer-copy exchange: recorded on this member's stream at the start of an exchange --
+                                                         // whatever was queued before (consumers of the PREVIOUS result in this member's gathered
+                                                         // buffer) is ordered before the other members' pushes into that buffer
     pf_ctx *ctx = nullptr;
     pf_flat *flat = nullptr;
     ncclComm_t comm = nullptr;
@@ -149,12 +152,22 @@ pf_status exchange_blocks(pf_multi *g, uint32_t *const *gathered, size_t words) 
         return PF_OK;
     }
     // direct copies: member r pushes its block into every other member's buffer on its own stream, then every stream
-    // waits for all pushes, so that whatever the caller enqueues next on a member's stream sees the complete result
+    // waits for all pushes, so that whatever the caller enqueues next on a member's stream sees the complete result.
+    // A push lands in ANOTHER member's buffer, which that member's stream may still be reading (a consumer of the previous
+    // call's result, a device-to-host copy of it): every member first records "my buffer is free" behind everything already
+    // queued on its stream, and a pusher waits for the target's event before it writes (write-after-read across streams).
+    const pf_status freed = g->run_all([&](Member &m) -> pf_status {
+        PF_GUARD(m.device);
+        PF_HIP(hipEventRecord(m.ev_free, m.stream));
+        return PF_OK;
+    });
+    if (freed != PF_OK) return freed;
     const pf_status pushed = g->run_all([&](Member &m) -> pf_status {
         PF_GUARD(m.device);
         const uint32_t *src = gathered[m.rank] + (size_t)m.rank * words;
         for (int t = 0; t < G; ++t) {
             if (t == m.rank) continue;
+            PF_HIP(hipStreamWaitEvent(m.stream, g->mem[t]->ev_free, 0));
             uint32_t *dst = gathered[t] + (size_t)m.rank * words;
             if (g->mem[t]->device == m.device) PF_HIP(hipMemcpyAsync(dst, src, words * 4, hipMemcpyDeviceToDevice, m.stream));
             else PF_HIP(hipMemcpyPeerAsync(dst, g->mem[t]->device, src, m.device, words * 4, m.stream));
@@ -191,6 +204,7 @@ pf_status pf_multi_destroy(pf_multi *g) {
         if (w->flat) (void)pf_flat_destroy(w->flat);
         if (w->stage) (void)hipFree(w->stage);
         if (w->ev_done) (void)hipEventDestroy(w->ev_done);
+        if (w->ev_free) (void)hipEventDestroy(w->ev_free);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         delete w;
     }
@@ -220,6 +234,7 @@ pf_status pf_multi_create(pf_multi **out, const int *devices, int n, int exchang
         hipError_t e = guard.err;
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_free, hipEventDisableTiming);
         if (e != hipSuccess) { pf_multi_destroy(g); return fail(PF_ERR_HIP, std::string("pf_multi_create: ") + hipGetErrorString(e)); }
     }
     if (g->exchange == PF_MULTI_PEER_COPY) {           // let members write into each other's memory (no-op on one device)

@@ -2,6 +2,7 @@
 // /root/reference/src/server/controllers/Query.cc:9-127 without Drogon or nlohmann.
 #include "../../include/server/wire.h"
 
+#include <algorithm>
 #include <array>
 #include <cerrno>
 #include <cmath>
@@ -406,31 +407,62 @@ std::string handle_pir_layout(const Server &server) {
            ",\"ringDegree\":" + std::to_string(Server::ENC_RING_DEGREE) + ",\"plainModulus\":" + std::to_string(Server::PIR_PLAIN_MODULUS) + "}";
 }
 
+// residues of every limb-polynomial must be canonical (< q_limb): what the device kernels assume of their inputs
+static void check_residues(const uint64_t *w, size_t n_limb_polys, uint32_t limbs_cycle, const char *what) {
+    constexpr size_t N = Server::ENC_RING_DEGREE;
+    // key layout [..][K = L + 1][N] cycles over L data primes + the special prime; ciphertext layout cycles over the L data primes
+    static constexpr uint64_t SPECIAL = 0xFFFFFEBC001ull;                  // SEAL BFVDefault(8192): the fifth prime
+    for (size_t p = 0; p < n_limb_polys; ++p) {
+        const uint32_t l = (uint32_t)(p % limbs_cycle);
+        const uint64_t q = l < Server::ENC_LIMBS ? Server::ENC_MODULI[l] : SPECIAL;
+        for (size_t i = 0; i < N; ++i)
+            if (w[p * N + i] >= q) throw std::out_of_range(std::string(what) + ": residue out of range (limb " + std::to_string(l) + ")");
+    }
+}
+
 std::string handle_precise_vector_pir_private(const Server &server, const std::string &body) {
-    // The Galois keys of the expansion (tens of megabytes) are sent once and kept for the requests that follow without
-    // "galoisKeys": one client session per server process, like the reference's single-client demo.
+    // The Galois keys of the expansion (tens of megabytes) are sent once per SESSION and kept for the requests that follow without
+    // "galoisKeys".  A client names its session with the optional string "session" (the reference's single-client demo sends
+    // none: session ""), so one client's keys never replace another's; at most MAX_SESSIONS key sets are kept (oldest dropped).
     static std::mutex key_lock;
-    static std::vector<uint64_t> session_keys;
+    static std::vector<std::pair<std::string, std::vector<uint64_t>>> sessions;
+    constexpr size_t MAX_SESSIONS = 8;
     const Json req = parse(body);
-    const size_t count = (size_t)req.at("count").as_int();
+    const int64_t count_in = req.at("count").as_int();
+    if (count_in <= 0 || (size_t)count_in > (size_t)NQUERY * K) throw std::out_of_range("count must be in [1, NQUERY * K]");
+    const size_t count = (size_t)count_in;
     constexpr size_t per = 2 * (size_t)Server::ENC_LIMBS * Server::ENC_RING_DEGREE;
     const size_t key_words = (size_t)server.pirLevels() * Server::ENC_LIMBS * 2 * (Server::ENC_LIMBS + 1) * Server::ENC_RING_DEGREE;
     std::vector<uint64_t> keys;
     {
-        std::lock_guard<std::mutex> g(key_lock);
-        const Json *k = nullptr;
+        const Json *k = nullptr, *sid = nullptr;
         if (req.kind == Json::Object)
-            for (const auto &kv : req.obj)
+            for (const auto &kv : req.obj) {
                 if (kv.first == "galoisKeys") k = &kv.second;
+                if (kv.first == "session") sid = &kv.second;
+            }
+        if (sid && sid->kind != Json::String) throw TypeError("session must be a string");
+        const std::string session = sid ? sid->s : std::string();
+        std::vector<uint64_t> fresh;
         if (k) {
             if (k->kind != Json::String) throw TypeError("galoisKeys must be a base64 string");
             const std::vector<uint8_t> raw = base64_decode(k->s);
             if (raw.size() != key_words * 8) throw std::out_of_range("galoisKeys: expected " + std::to_string(key_words * 8) + " bytes, got " + std::to_string(raw.size()));
-            session_keys.resize(key_words);
-            std::memcpy(session_keys.data(), raw.data(), raw.size());
+            fresh.resize(key_words);
+            std::memcpy(fresh.data(), raw.data(), raw.size());
+            check_residues(fresh.data(), key_words / Server::ENC_RING_DEGREE, Server::ENC_LIMBS + 1, "galoisKeys");
         }
-        if (session_keys.size() != key_words) throw std::out_of_range("precise-vector-pir-private: no Galois keys in this request and none kept from an earlier one");
-        keys = session_keys;
+        std::lock_guard<std::mutex> g(key_lock);
+        auto it = std::find_if(sessions.begin(), sessions.end(), [&](const auto &e) { return e.first == session; });
+        if (k) {
+            if (it != sessions.end()) sessions.erase(it);
+            if (sessions.size() >= MAX_SESSIONS) sessions.erase(sessions.begin());
+            sessions.emplace_back(session, std::move(fresh));
+            it = sessions.end() - 1;
+        }
+        if (it == sessions.end() || it->second.size() != key_words)
+            throw std::out_of_range("precise-vector-pir-private: no Galois keys in this request and none kept for this session");
+        keys = it->second;
     }
     const Json &blob = req.at("queryCiphertexts");
     if (blob.kind != Json::String) throw TypeError("queryCiphertexts must be a base64 string");
@@ -438,6 +470,7 @@ std::string handle_precise_vector_pir_private(const Server &server, const std::s
     if (raw.size() != count * per * 8) throw std::out_of_range("queryCiphertexts: expected " + std::to_string(count * per * 8) + " bytes, got " + std::to_string(raw.size()));
     std::vector<uint64_t> in(count * per), out(count * server.pirCols() * per);
     std::memcpy(in.data(), raw.data(), raw.size());
+    check_residues(in.data(), count * 2 * Server::ENC_LIMBS, Server::ENC_LIMBS, "queryCiphertexts");
     server.preciseVectorPIRPrivateHost(in.data(), count, keys.data(), out.data());
     return "{\"replyCiphertexts\":\"" + base64_encode(out.data(), out.size() * 8) + "\"}";
 }

@@ -562,3 +562,46 @@ def test_exact16_query_tile_falls_back_per_tile():
     assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
     Dr, Ir = oracle.flat_l2_search(xb, xq[:128], 50)
     assert (got16[1][:128] == Ir).all() and (got16[0][:128] == Dr).all()
+
+
+@pytest.mark.parametrize("law", ["uint8", "gauss"])
+def test_bf16_paths_with_nonfinite_and_huge_queries(law):
+    """NaN, +Inf, -Inf and 1e30 inside query rows: the bf16 tiles (exact path over an 8-bit-valued base, conservative filter
+    over a Gaussian one) must return what the fp32-operand tiles return, bit for bit, for those queries and for their finite
+    neighbours in the same 128-query tile and in other tiles."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(4242)
+    nb, nq, k = 70000, 300, 50
+    if law == "uint8":
+        xb = rng.integers(0, 256, (nb, 128)).astype(np.float32)
+        xq = rng.integers(0, 256, (nq, 128)).astype(np.float32)
+    else:
+        xb = rng.standard_normal((nb, 128)).astype(np.float32)
+        xq = rng.standard_normal((nq, 128)).astype(np.float32)
+    xq[3, 5] = np.nan
+    xq[3, 77] = -np.nan
+    xq[40, 0] = np.inf
+    xq[41, 127] = -np.inf
+    xq[130, 64] = 1e30
+    xq[131, 1] = -3e38
+    xq[200, :] = np.nan
+    xq[299, 10] = np.float32(np.uint32(0x7F800001).view(np.float32))        # a signalling NaN pattern
+    flat = pf.FlatL2(xb, dev)
+    assert flat.operands16() == (2 if law == "uint8" else 1)
+    dq = torch.from_numpy(xq).to(dev)
+    D16, I16 = flat.search(dq, k)
+    flat.operands16(0)
+    D32, I32 = flat.search(dq, k)
+    torch.cuda.synchronize()
+    assert torch.equal(I16, I32)
+    assert torch.equal(D16.view(torch.int32), D32.view(torch.int32))
+    # the finite queries also match the oracle
+    fin = [i for i in range(nq) if np.isfinite(xq[i]).all() and np.abs(xq[i]).max() < 1e20][:6]
+    Dr, Ir = oracle.flat_l2_search(xb, xq[fin], k)
+    got_I, got_D = I32.cpu().numpy()[fin], D32.cpu().numpy()[fin]
+    assert (got_I == Ir).all()
+    if law == "uint8":
+        assert (got_D == Dr).all()
+    else:
+        assert np.allclose(got_D, Dr, rtol=RTOL, atol=0)

@@ -273,6 +273,52 @@ def test_config5_key_switch_batch_256(pf):
     assert (got[sel == 0] == exp3[0]).all()
 
 
+def test_config5_ct_pt_batch_256(pf):
+    """BASELINE config 5's fused ct x pt at its batch size (256 ciphertexts x 15 limbs at N=32768): rows 0, 17 and 255 are
+    independent random ciphertexts / plaintexts checked against the oracle, the others repeat row 0 and must equal its result."""
+    N, qs, B = 32768, oracle.BFV_DEFAULT[32768][:15], 256
+    rng = np.random.default_rng(20250801 + 555)
+    o = oracle.Oracle(N, qs)
+    c = _ctx(pf, N, qs)
+    ct3 = np.stack([rng.integers(0, q, (3, 2, N), dtype=np.uint64) for q in qs], axis=2)
+    pt3 = np.stack([rng.integers(0, q, (3, N), dtype=np.uint64) for q in qs], axis=1)
+    exp3 = o.ct_pt_mul(ct3, pt3)
+    rows = {0: 0, 17: 1, 255: 2}
+    sel = torch.from_numpy(np.array([rows.get(b, 0) for b in range(B)])).to(_dev())
+    d_ct = pf.to_device_u64(ct3, _dev())[sel].contiguous()
+    d_pt = pf.to_device_u64(pt3, _dev())[sel].contiguous()
+    got = pf.to_host_u64(c.ct_pt_mul(d_ct, d_pt))
+    for b in (0, 17, 255, 1, 128, 254):
+        assert (got[b] == exp3[rows.get(b, 0)]).all(), b
+    others = np.array([b for b in range(B) if b not in rows])
+    assert (got[others] == exp3[0]).all()
+
+
+def test_key_switch_reserved_is_graph_capturable(pf):
+    """After pf_key_switch_reserve the call neither allocates nor synchronises nor reads the environment: the two-pass path at
+    N=32768 (and the single-kernel path at N=8192) is captured into a hipGraph, replayed on fresh inputs, checked against the oracle."""
+    for N, qs, B in ((32768, oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:], 2), (8192, oracle.BFV_DEFAULT[8192], 3)):
+        K, D = len(qs), len(qs) - 1
+        rng = np.random.default_rng(N + 17)
+        o = oracle.Oracle(N, qs)
+        c = _ctx(pf, N, qs)
+        c.key_switch_reserve(B)
+        ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+        d_ksk = pf.to_device_u64(ksk, _dev())
+        d_t = torch.empty((B, D, N), dtype=torch.int64, device=_dev())
+        d_c = torch.empty((B, 2, D, N), dtype=torch.int64, device=_dev())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):                       # first call is INSIDE the capture: nothing may allocate
+            c.key_switch_(d_t, d_ksk, d_c)
+        for _ in range(2):
+            target = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs[:D]], axis=1)
+            ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs[:D]], axis=2)
+            d_t.copy_(pf.to_device_u64(target, _dev())); d_c.copy_(pf.to_device_u64(ct, _dev()))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert (pf.to_host_u64(d_c) == o.key_switch(target, ksk, ct)).all(), N
+
+
 def test_errors_are_statuses(pf):
     c = _ctx(pf, 1024, oracle.BFV_DEFAULT[1024])
     with pytest.raises(pf.PfError):

@@ -25,3 +25,7 @@ def test_client_bfv_and_encrypted_precise_search():
     assert os.path.exists(exe), "tests/cpp/test_bfv missing: run __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "test_bfv: OK" in r.stdout, r.stdout + r.stderr
+    # round 4 with private ids went through wire::handle (route precise-vector-pir-private, transport = the in-process link):
+    # the binary EXPECTs the rows bit-identical to the reference's plain round before it prints this line
+    assert "private retrieval over the wire format:" in r.stdout, r.stdout
+    assert "encrypted round over the wire format:" in r.stdout, r.stdout

@@ -85,6 +85,37 @@ def test_selectable_geometry_1024x32_at_n32768(sim_lib_1024x32, q, arith):
     assert lib.pf_sim_range_violations() == 0
 
 
+@pytest.mark.parametrize("qs", [oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:],
+                                [0x7FFFFFFF380001, 0x3FFFFFFF000001, 0xFFFFFFFFF70001]])          # mixed widths: a 54-bit modulus among 55/56-bit ones
+def test_two_pass_key_switch_core_on_host_simulator(sim_lib, qs):
+    """prefhetch_amd/csrc/ks_split.hpp (the two-pass digit transforms of key switching at N = 32768: pass A = stages 0..6 on
+    128 x 64 tiles, pass B = stages 7..14 + 128-bit multiply-accumulate with the key, per half-wave) executed on the host, one OS
+    thread per lane: acc[c][J] = sum_I NTT_J(target_I mod m_J) . ksk[I][c][J], bit for bit against the oracle; digits are taken
+    WITHOUT reduction modulo m_J (the lazy butterflies' range analysis must hold: zero violations)."""
+    N = 32768
+    K, D = len(qs), len(qs) - 1
+    assert all((q - 1) % (2 * N) == 0 for q in qs)
+    rng = np.random.default_rng(K * 1000 + D)
+    target = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:D]])
+    target[0, :7] = qs[0] - 1
+    target[1, -3:] = qs[1] - 1
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(D)])
+    ksk[0, 0, :, :4] = (np.array(qs, dtype=np.uint64) - 1)[:, None]
+    acc = np.zeros((2, K, N), dtype=np.uint64)
+    mods = np.array(qs, dtype=np.uint64)
+    assert sim_lib.pf_sim_ks_split(D, K, _p(mods), _p(target), _p(ksk), _p(acc)) == 0
+    for J, q in enumerate(qs):
+        o = oracle.Oracle(N, [q])
+        exp = [np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)]
+        for I in range(D):
+            xt = o.ntt_forward(target[I] % np.uint64(q))
+            for c in range(2):
+                exp[c] = o.addsub(exp[c], o.dyadic_mul(xt, ksk[I, c, J]), 0)
+        for c in range(2):
+            assert (acc[c, J] == exp[c]).all(), (J, c)
+    assert sim_lib.pf_sim_range_violations() == 0
+
+
 def test_simulator_golden_n1024(sim_lib, golden):
     for ci in (4, 5):
         g = lambda k: golden[f"c{ci}_{k}"]

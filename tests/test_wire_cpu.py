@@ -132,3 +132,49 @@ def test_http_listener_serves_a_stock_http_client():
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def test_http_listener_is_not_blocked_by_idle_or_stalled_clients():
+    """one half-open socket must not deny service.  While an idle keep-alive connection and a connection that has sent
+    half a request head AND one that has sent half a body stay open, a third client is served at once; the stalled ones then
+    complete their requests on the same sockets and are served too (one poll set, no blocking recv)."""
+    import http.client
+    import socket
+    import time
+    n = 5
+    p = subprocess.Popen([BIN, "http", str(n)], stdout=subprocess.PIPE, text=True)
+    try:
+        port = int(p.stdout.readline().split()[1])
+        idle = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
+        idle.request("GET", "/query")                                   # request 1, then the connection idles (keep-alive)
+        assert idle.getresponse().read()
+        half_head = socket.create_connection(("127.0.0.1", port))
+        half_head.sendall(b"POST /echo HTTP/1.1\r\nHost: x\r\nContent-Le")
+        half_body = socket.create_connection(("127.0.0.1", port))
+        half_body.sendall(b"POST /echo HTTP/1.1\r\nHost: x\r\nContent-Length: 10\r\n\r\n01234")
+        time.sleep(0.3)
+        t0 = time.time()
+        c = http.client.HTTPConnection("127.0.0.1", port, timeout=10)
+        c.request("POST", "/echo", body="hello")                         # request 2
+        r = c.getresponse()
+        assert r.status == 200 and r.read() == b"hello"
+        assert time.time() - t0 < 2.0, "a stalled client kept the listener busy"
+        half_head.sendall(b"ngth: 3\r\n\r\nabc")                         # request 3 completes on its own socket
+        resp = b""
+        while b"abc" not in resp:
+            resp += half_head.recv(4096)
+        assert resp.startswith(b"HTTP/1.1 200")
+        half_body.sendall(b"56789")                                      # request 4
+        resp = b""
+        while b"0123456789" not in resp:
+            resp += half_body.recv(4096)
+        assert resp.startswith(b"HTTP/1.1 200")
+        idle.request("GET", "/query")                                   # request 5 on the connection that idled meanwhile
+        assert idle.getresponse().status == 200
+        out, _ = p.communicate(timeout=30)
+        assert f"served {n}" in out
+        for s_ in (half_head, half_body):
+            s_.close()
+    finally:
+        if p.poll() is None:
+            p.kill()

@@ -14,7 +14,11 @@ for pass in "a:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
   bash tools/pmc_pass.sh ${tag}_ctpt_${pass%%:*} "${pass#*:}" ctpt 30 1024 > $O/${tag}_pmc_ctpt_${pass%%:*}.txt 2>&1
 done
 bash tools/pmc_flat.sh ${tag}_flat 3 1024 > $O/${tag}_pmc_flat_tiles.txt 2>&1
-[ -f exp_libs/libpf_fs.so ] && PREFHETCH_HIP_LIB=$R/exp_libs/libpf_fs.so python3 tools/flat_stamps.py > $O/${tag}_flat_stamps.txt 2>&1
+# phase stamps need a library built with -DPF_FLAT_STAMPS: built HERE, from this snapshot's sources, into /tmp (never a stale
+# library carried along in the tree)
+if make -C prefhetch_amd/csrc -j16 BUILD=/tmp/pf_build_stamps OUT=/tmp/pf_stamps/libprefhetch_hip.so EXTRA=-DPF_FLAT_STAMPS /tmp/pf_stamps/libprefhetch_hip.so > $O/${tag}_stamps_build.log 2>&1; then
+  PREFHETCH_HIP_LIB=/tmp/pf_stamps/libprefhetch_hip.so python3 tools/flat_stamps.py > $O/${tag}_flat_stamps.txt 2>&1
+fi
 python3 tools/time_flat_gauss.py > $O/${tag}_flat_gaussian.txt 2>&1
 python3 tools/sweep_shapes.py > $O/${tag}_shapes_sweep.json 2> $O/${tag}_shapes_sweep.err
 python3 tools/sweep_flat.py > $O/${tag}_flat_sweep.json 2> $O/${tag}_flat_sweep.err
@@ -27,3 +31,6 @@ cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_enc -name "*kernel_
 tail -2 $O/${tag}_encround.txt
 [ -x tools/time_pir ] && timeout -k 10 400 tools/time_pir 262144 2 > $O/${tag}_pir_262144_rows.json 2> $O/${tag}_pir.err
 cat $O/${tag}_bench.json | head -c 600; echo
+# a step that printed a traceback produced no measurement: say so loudly and fail
+bad=$(grep -l "Traceback (most recent call last)" $O/${tag}_* 2>/dev/null)
+if [ -n "$bad" ]; then echo "prof_round.sh: THESE FILES HOLD A TRACEBACK, NOT A MEASUREMENT:"; echo "$bad"; exit 1; fi
