@@ -577,9 +577,10 @@ __global__ void __launch_bounds__(GEO::THREADS, 2) k_l2_tile(TileArgs p) {
 // same tiles as a conservative filter -- margin 1.05 x 2^-8 (|x|^2 + |y|^2) on the thresholds, the survivors' distances by
 // the fp32 chain over the fp32 rows (flush) -- and fp32 tiles where that filter cannot help (k_l2_tile16, select_one).
 struct Pend16 {
-    static constexpr uint32_t CAP = 1112;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
+    static constexpr uint32_t CAP = 1760;     // 2 x 34 KiB of operands + 2 KiB of rows + this list fit twice into a CU's 160 KiB
+    static constexpr uint32_t HIGH = CAP * 3 / 4;   // a list longer than this is worked off at once; a shorter one waits for more (pend16_flush)
     uint32_t id[CAP];                  // base row
-    uint32_t loc[CAP];                 // local query row
+    uint8_t loc[CAP];                  // local query row
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
 };
@@ -610,7 +611,7 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 #endif
 template <int D, int MT, int NJ>
 __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
-                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid,
+                                             uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -622,7 +623,11 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
     PF_FLSTAMP(0);
-    while (__syncthreads_or(left != 0)) {                         // (the barrier: the list is empty, every row count zero)
+    // Parking (LDS only) happens at every call; the expensive part -- barriers, a returning global atomic per row, the rows of
+    // every survivor fetched again -- only once the list is long (HIGH), overflowed (a lane could not park everything), or the
+    // walk ends (`final`).  In the long late chunks a workgroup parks ~90 survivors per call: it now pays for ONE round trip to
+    // memory per walk instead of one per MT tiles (the flushes were 35 % of the tile kernels' time: profiles/r03_flat_ablation.txt).
+    for (;;) {
         PF_FLSTAMP(1);
         uint32_t slot = left ? atomicAdd(&pd.n, left) : 0u;
         uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
@@ -641,7 +646,7 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                     const int s = 31 - b, r = s & 15;
                     const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                     pd.id[slot] = id;
-                    pd.loc[slot] = lrow;
+                    pd.loc[slot] = (uint8_t)lrow;
                     atomicAdd(&pd.rcnt[lrow], 1u);                      // no return value: the position inside the row is drawn when the key is written
                     ++slot; --take;
                 };
@@ -653,8 +658,10 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 surv[u][jj] = m;
             }
         PF_FLSTAMP(2);
-        __syncthreads();
+        const bool any_left = __syncthreads_or(left != 0) != 0;          // (the barrier: everything parked is visible)
         PF_FLSTAMP(3);
+        const uint32_t have = pd.n;
+        if (have == 0 || (!any_left && !final && have <= Pend16::HIGH)) return;      // workgroup-uniform: the list waits for more
         const uint32_t n = pd.n < Pend16::CAP ? pd.n : Pend16::CAP;
         if (approx) {                                                 // workgroup-uniform
             // inexact operands: the distance of a survivor is the k-ordered fp32 chain over the fp32 rows -- what the fp32 tiles
@@ -701,6 +708,8 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             }
             __syncthreads();
             if (tid == 0) pd.n = 0;
+            __syncthreads();                                          // the reset is visible before anyone parks again
+            if (!any_left) return;
             continue;
         }
         // U survivors per group and pass: their rows are requested first, and in the first pass the per-row reservations (a
@@ -756,8 +765,9 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
         PF_FLSTAMP(6);
         __syncthreads();
         if (tid == 0) pd.n = 0;
+        __syncthreads();                                              // the reset is visible before anyone parks again
+        if (!any_left) return;
     }
-    PF_FLSTAMP(7);
 }
 
 // FILTER epilogue of the bf16 tiles: the accumulators hold the filter value (above), a distance can pass only where the sign
@@ -780,6 +790,9 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 
 #ifndef PF_FLAT_MT
 #define PF_FLAT_MT 8
+#endif
+#ifndef PF_DMA_SPREAD
+#define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
 template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
 __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
@@ -827,16 +840,20 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
     // Tile t+1 is requested at the top of tile t, into the buffer whose readers passed the barrier that ended tile t-1, and
     // waited for (vmcnt(0)) before the barrier that ends tile t.
     float bn_next[NJ];
-    auto stage_b = [&](uint32_t ct, char *buf) {
+    // sweep `it` (0 .. SWEEPS: the last one is the remainder) of column tile ct into buf
+    auto stage_sweep = [&](uint32_t ct, char *buf, uint32_t it) {
         const char *src = reinterpret_cast<const char *>(p.xb16 + (p.nb_first + (size_t)ct * TN) * (size_t)(D + AUX16)) + tid * 16;
         char *dst = buf + wave * 1024;
-#pragma unroll
-        for (uint32_t it = 0; it < SWEEPS; ++it)
+        if (it < SWEEPS)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4096 * it),
                                              (__attribute__((address_space(3))) void *)(dst + 4096 * it), 16, 0, 0);
-        if (REM && (uint32_t)tid < REM)
+        else if (REM && (uint32_t)tid < REM)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4096 * SWEEPS),
                                              (__attribute__((address_space(3))) void *)(dst + 4096 * SWEEPS), 16, 0, 0);
+    };
+    auto stage_b = [&](uint32_t ct, char *buf) {
+#pragma unroll
+        for (uint32_t it = 0; it <= SWEEPS; ++it) stage_sweep(ct, buf, it);
     };
     auto fetch_bn = [&](uint32_t ct) {                               // column norms: the unfiltered (bootstrap) epilogue forms distances
         const size_t c0 = (size_t)ct * TN;
@@ -914,7 +931,16 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
         const uint32_t u = (ct - ct0) % MT, cur = (ct - ct0) & 1u;
         char *const buf_cur = cur ? sB16_1 : sB16_0, *const buf_nxt = cur ? sB16_0 : sB16_1;
         PF_FSTAMP(0);
-        if (ct + 1 < ct1) stage_b(ct + 1, buf_nxt);                   // in flight under this tile's matrix work and epilogue
+        // The copies of tile ct+1 are requested BETWEEN the matrix instructions of this tile, a sweep per k-step (PF_DMA_SPREAD): a
+        // copy instruction holds the wave's issue for ~60-80 cycles; all nine at the top of the tile were 690 cycles in which this
+        // wave fed nothing to the matrix pipe, one behind the first matrix instruction of a k-step hides under the 128 cycles the
+        // step's four instructions occupy the pipe for.
+        const bool more = ct + 1 < ct1;                                // workgroup-uniform
+#ifdef PF_ABL_NODMA   // ablation (timing only, wrong results): no copies after the walk's second tile
+        if (more && ct < ct0 + 1) stage_b(ct + 1, buf_nxt);
+#elif !PF_DMA_SPREAD
+        if (more) stage_b(ct + 1, buf_nxt);                           // in flight under this tile's matrix work and epilogue
+#endif
         PF_FSTAMP(1);
         const size_t c0 = (size_t)ct * TN;
         size_t col[NJ]; bool col_ok[NJ]; float bnv[NJ];
@@ -950,10 +976,28 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
                 for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fbx + 32 * jj * PITCH + D * 2);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if PF_DMA_SPREAD && !defined(PF_ABL_NODMA)
+            // sweeps ks and (for the last step, when D / 16 < SWEEPS + 1) the rest, behind the step's first matrix instruction
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[0][ks], b[c][0], acc[0][0], 0, 0, 0);
+            if (more) {
+                constexpr uint32_t STEPS = D / 16;
+                if ((uint32_t)ks + 1 < STEPS) stage_sweep(ct + 1, buf_nxt, ks);
+                else {
+#pragma unroll
+                    for (uint32_t it = STEPS - 1; it <= SWEEPS; ++it) stage_sweep(ct + 1, buf_nxt, it);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+                    if (i || jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
+#else
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (FILTER) {
@@ -968,7 +1012,11 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             uint32_t s1[NJ];
             l2_tile_verdicts16<GEO>(acc, col_ok, s1);
 #pragma unroll
+#ifdef PF_ABL_NOSURV   // ablation (timing only, wrong results): the verdicts are computed and dropped -- nothing to flush
+            for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj] & (p.nq == 0xFFFFFFFFu ? ~0u : 0u);
+#else
             for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj];   // wave-uniform index: v_movreld
+#endif
             PF_FSTAMP(4);
         } else {
             // q0 made opaque per tile: otherwise hipcc hoists the row addresses of the slab stores out of the tile loop
@@ -976,8 +1024,10 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
             asm volatile("" : "+s"(q0t));
             l2_tile_epilogue<false, GEO, false>(p, acc, stage, q0t, wm, tid, col, col_ok, bnv, row_qn, row_tau);
         }
+#ifndef PF_ABL_NOBAR   // ablation (timing only, wrong results): no per-tile barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of tile ct+1 have landed
         __syncthreads();                                                // the tile's one barrier: the other buffer is complete
+#endif
         PF_FSTAMP(5);
         if constexpr (FILTER) {
             if (u == MT - 1 || ct + 1 == ct1) {                         // workgroup-uniform
@@ -985,7 +1035,7 @@ __global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
-                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
