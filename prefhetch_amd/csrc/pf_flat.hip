@@ -615,7 +615,8 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                                              uint32_t flush_no = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-    constexpr uint32_t L = D / 8, G = 256 / L;                    // lanes per survivor (16 bytes of both rows each), survivors per pass
+    // lanes per survivor: LU = D / 8 of them hold 16 bytes of both rows each, rounded up to a power of two (L) for the DPP sum
+    constexpr uint32_t LU = D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : 16, G = 256 / L;         // G survivors per pass
     const int lane = tid & 63;
     uint32_t left = 0;
 #pragma unroll
@@ -724,8 +725,12 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             for (int u = 0; u < U; ++u) {
                 const uint32_t e = e0 + u * G + g < n ? e0 + u * G + g : n - 1;     // idle groups of the last pass repeat the last survivor
                 loc[u] = pd.loc[e]; id[u] = pd.id[e];
-                va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + loc[u]) * (size_t)D + 8 * l);
-                vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
+                if (LU == L || l < LU) {
+                    va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + loc[u]) * (size_t)D + 8 * l);
+                    vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
+                } else {
+                    va[u] = u32x4{0, 0, 0, 0}; vb[u] = u32x4{0, 0, 0, 0};          // lanes past the row (D / 8 not a power of two)
+                }
                 bnv[u] = p.bn[id[u]];
             }
             if (e0 == 0) {                                            // workgroup-uniform
@@ -752,8 +757,8 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 }
                 // sum over the L lanes of the group (DPP: quad permutes, then mirrors within 8 and 16 lanes): every lane ends with the total
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
+                if constexpr (L >= 4) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+                if constexpr (L >= 8) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
                 if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
                 if (pos[u] < p.cap) {                                 // (~0 for idle lanes and groups)
                     const uint32_t row = loc[u];
@@ -1699,7 +1704,9 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     if (e == hipSuccess && nb) {
         // row norms; and, where the shape allows the bf16 loop, the 16-bit image with its value-by-value exactness check
         uint32_t *flag = nullptr;
-        const bool try16 = (d == 64 || d == 128) && getenv("PF_FLAT_NO_BF16") == nullptr;
+        // every row length that is a multiple of the matrix instruction's k-step up to 128 (k_rows_prep stages whole rows in LDS
+        // up to PREP_MAX_D = 128; the query fragments of a 128-row tile fill 64 registers at d = 128: twice that does not fit)
+        const bool try16 = d % 16 == 0 && d <= 128 && getenv("PF_FLAT_NO_BF16") == nullptr;
         // image rows carry AUX16 threshold words behind their d values; one tile of zero rows pads the end (k_l2_tile16 copies whole tiles)
         const size_t bytes16 = (nb + 128) * (size_t)(d + AUX16) * 2;
         if (try16 && (hipMalloc((void **)&f->xb16, bytes16) != hipSuccess || hipMemset(f->xb16, 0, bytes16) != hipSuccess ||
@@ -1826,12 +1833,12 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             const size_t n_groups = (nct + group - 1) / group;
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
-            if (f->d == 128) {
-                if (filter) hipLaunchKernelGGL((k_l2_tile16<true, 128>), grid16, dim3(256), 0, s, t, g32, n32);
-                else hipLaunchKernelGGL((k_l2_tile16<false, 128>), grid16, dim3(256), 0, s, t, g32, n32);
-            } else {
-                if (filter) hipLaunchKernelGGL((k_l2_tile16<true, 64>), grid16, dim3(256), 0, s, t, g32, n32);
-                else hipLaunchKernelGGL((k_l2_tile16<false, 64>), grid16, dim3(256), 0, s, t, g32, n32);
+            switch (f->d) {
+#define PF_T16(DD) case DD: if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \
+                            else hipLaunchKernelGGL((k_l2_tile16<false, DD>), grid16, dim3(256), 0, s, t, g32, n32); break;
+                PF_T16(16) PF_T16(32) PF_T16(48) PF_T16(64) PF_T16(80) PF_T16(96) PF_T16(112) PF_T16(128)
+#undef PF_T16
+                default: break;                                       // (pf_flat_create keeps an image for these row lengths only)
             }
             return;
         }

@@ -398,7 +398,8 @@ def _search_both(pf, xb, xq, k):
     return active, (D1.cpu().numpy(), I1.cpu().numpy()), (D0.cpu().numpy(), I0.cpu().numpy())
 
 
-@pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (128, 1024, 100), (64, 65, 64)])
+@pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (128, 1024, 100), (64, 65, 64),
+                                    (16, 200, 33), (32, 257, 100), (48, 130, 200), (80, 300, 50), (96, 513, 100), (112, 129, 17)])   # every multiple of 16 up to 128
 def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
     """exactly-representable data (integers, |v| <= 256): the bf16-operand tiles must return the fp32 loop's (D, I) and the
     oracle's, bit for bit -- including the extreme values +-256 and heavy ties"""
@@ -481,7 +482,8 @@ def test_bf16_filter_over_inexact_operands_is_bit_identical(law):
 
 @pytest.mark.parametrize("nb,nq,k,d,law", [(100, 200, 50, 128, "int"), (8192, 130, 20, 128, "int"), (8193, 130, 20, 128, "int"), (20000, 65, 1024, 128, "int"),
                                             (50000, 300, 1024, 64, "int"), (30000, 129, 7, 64, "gauss"), (9000, 70, 200, 128, "gauss"),
-                                            (70000, 257, 300, 128, "mixed")])
+                                            (70000, 257, 300, 128, "mixed"), (60000, 300, 100, 96, "gauss"), (60000, 200, 40, 48, "mixed"),
+                                            (40000, 129, 64, 16, "gauss"), (50000, 260, 200, 112, "int"), (50000, 140, 10, 80, "gauss")])
 def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
     """shapes around the seams of the batch path: a base smaller than one tile, exactly / one past the bootstrap chunk, the smallest
     batch, k = 1024 (merges of 2048 keys by one wave), d = 64, a single filtered tile -- bf16 tiles vs fp32 operands, bit for bit"""
