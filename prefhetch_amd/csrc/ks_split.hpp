@@ -69,6 +69,50 @@ PF_HD void ks_fwd_stage(typename A::V (&r)[NR], const A &ar, TwFn &&twf) {
     });
 }
 
+// One inverse (Gentleman-Sande) stage over NR registers: (x, y) -> (x + y, (x - y) * w), w = twf(b >> KB) from the INVERSE table
+// (same entry index as the forward stage it undoes).  J = stages since the values were last below 4q (ArithU64L's contract:
+// stage J sees values below 4q * 2^J and keeps the differences' products below 4q).
+template <int NR, int KB, int J, bool UTW, class A, class TwFn>
+PF_HD void ks_inv_stage(typename A::V (&r)[NR], const A &ar, TwFn &&twf) {
+    using V = typename A::V;
+    static_for<0, NR / 2, 4>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
+        V xs[4], yi[4], ds[4];
+        typename A::TwR ts[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            xs[i] = r[k0]; yi[i] = r[k0 | (1 << KB)];
+            ts[i] = twf(b >> KB);
+        }
+        ar.template inv_split_n<J, 4>(xs, yi, ds);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            r[k0] = xs[i];
+        }
+        ar.template mul_tw_n<4, UTW>(ds, ts);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i, k0 = ((b >> KB) << (KB + 1)) | (b & ((1 << KB) - 1));
+            r[k0 | (1 << KB)] = ds[i];
+        }
+    });
+}
+
+template <int NR, class A>
+PF_HD void ks_reduce_all(typename A::V (&r)[NR], const A &ar) {          // any value below 2^64 -> [0, 2q)
+    static_for<0, NR, 8>([&](auto bbc) {
+        constexpr int bb = decltype(bbc)::value;
+        typename A::V v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r[bb + i];
+        ar.template pass_reduce_n<8>(v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[bb + i] = v[i];
+    });
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Pass A: stages 0..6 of one (digit, modulus) transform on the tile of columns [64 cb, 64 cb + 64).
 //   src  the digit polynomial (coefficient form, residues of ITS modulus: any value below 2^56)
@@ -240,10 +284,11 @@ PF_HD void ksb_finish_fwd(uint64_t (&r)[8], const A &ar, const KsbTw &T, int l, 
 
 // x        pass A's output for (this ciphertext, digit 0, this modulus); digit I sits at x + I * x_stride
 // ksk      key for (digit 0, component 0, this modulus): component c of digit I at ksk + (2 I + c) * k_stride
-// out0/1   accumulated products of the two components for (this ciphertext, this modulus), NTT form, canonical
+// out0/1   accumulated products of the two components for (this ciphertext, this modulus): NTT form, canonical (INV = false), or
+//          after the first eight inverse stages, reduced to [0, 2q), natural index order (INV = true: pass C continues)
 // chunk    which 2048 coefficients (0..15) this workgroup covers
-template <class A, class WSync>
-PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *__restrict__ x, size_t x_stride,
+template <class A, bool INV, class WSync>
+PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const TwU64 *__restrict__ itw, const uint64_t *__restrict__ x, size_t x_stride,
                     const uint64_t *__restrict__ ksk, size_t k_stride, uint64_t *__restrict__ out0, uint64_t *__restrict__ out1, int D, int chunk,
                     uint64_t *lds, int tid, WSync &&wsync) {
     static_assert(std::is_same<typename A::V, uint64_t>::value, "the split key switch runs the 64-bit lazy family");
@@ -302,24 +347,171 @@ PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const uint64_t *_
                 for (int e = 0; e < 4; ++e) { lo[c][4 * g + e] = l4[e]; hi[c][4 * g + e] = h4[e]; }
             }
     }
-    // one Barrett reduction per sum; stores staged through the half-wave's area so that every store instruction covers 512
-    // contiguous bytes (a lane owns 64 consecutive bytes: stored directly that is a 64-byte lane stride, 0.93 against 3.27 TB/s)
+    if constexpr (!INV) {
+        // one Barrett reduction per sum; stores staged through the half-wave's area so that every store instruction covers 512
+        // contiguous bytes (a lane owns 64 consecutive bytes: stored directly that is a 64-byte lane stride, 0.93 against 3.27 TB/s)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
+        for (int c = 0; c < 2; ++c) {
+            U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint64_t v0 = ar.barrett128(lo[c][2 * j], hi[c][2 * j]), v1 = ar.barrett128(lo[c][2 * j + 1], hi[c][2 * j + 1]);
-            wr[j] = U64x2{v0 >= ar.q ? v0 - ar.q : v0, v1 >= ar.q ? v1 - ar.q : v1};
+            for (int j = 0; j < 4; ++j) wr[j] = U64x2{ar.barrett128(lo[c][2 * j], hi[c][2 * j]), ar.barrett128(lo[c][2 * j + 1], hi[c][2 * j + 1])};
+            wsync();
+            uint64_t *o = (c ? out1 : out0) + base;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = 2 * (32 * j + l);                          // coefficient pair number 32 j + l
+                *reinterpret_cast<U64x2 *>(o + cc) = *reinterpret_cast<const U64x2 *>(area + ksb_p2(cc));
+            }
+            wsync();
         }
-        wsync();
-        uint64_t *o = (c ? out1 : out0) + base;
+    } else {
+        // INV: the first eight stages of the INVERSE transform of both sums run here too -- they act inside the same 256-point
+        // blocks, in the reverse order of the layouts (R3: stages 14, 13, 12; R2: 11, 10, 9; R1: 8, 7), with the twiddles of the
+        // inverse table at the same 17 entries.  The block leaves in R1 order (16 bytes per lane, 512 per half-wave), reduced to
+        // [0, 2q): pass C finishes stages 6..0 over the columns and divides by the special prime.
+        T.load(itw, blk, l);
+        const int hi2 = l >> 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cc = 2 * (32 * j + l);                          // coefficient pair number 32 j + l
-            *reinterpret_cast<U64x2 *>(o + cc) = *reinterpret_cast<const U64x2 *>(area + ksb_p2(cc));
+        for (int c = 0; c < 2; ++c) {
+            uint64_t r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = ar.barrett128(lo[c][e], hi[c][e]);
+            ks_inv_stage<8, 0, 0, false>(r, ar, [&](int g) { return T.s14[g]; });
+            ks_inv_stage<8, 1, 1, false>(r, ar, [&](int g) { return T.s13[g]; });
+            ks_inv_stage<8, 2, 2, false>(r, ar, [&](int) { return T.s12; });
+            {   // exchange 2 backwards: R3 (lane l owns c = 8 l + k) -> R2
+                U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wr[j] = U64x2{r[2 * j], r[2 * j + 1]};
+                wsync();
+                const uint64_t *rd = area + ksb_p2(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = rd[10 * k];
+            }
+            ks_inv_stage<8, 0, 3, false>(r, ar, [&](int g) { return T.s11[g]; });
+            ks_inv_stage<8, 1, 4, false>(r, ar, [&](int g) { return T.s10[g]; });
+            ks_inv_stage<8, 2, 5, false>(r, ar, [&](int) { return T.s9; });
+            ks_reduce_all<8>(r, ar);
+            wsync();                                                 // exchange 2 read out
+            {   // exchange 1 backwards: R2 -> R1
+                uint64_t *wr = area + ksb_p1(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wr[8 * k] = r[k];
+                wsync();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const U64x2 v = *reinterpret_cast<const U64x2 *>(area + ksb_p1(128 * (kk >> 1) + 64 * (kk & 1)) + 2 * l);
+                    r[2 * kk] = v.x; r[2 * kk + 1] = v.y;
+                }
+            }
+            ks_inv_stage<8, 1, 0, false>(r, ar, [&](int g) { return T.s8[g]; });
+            ks_inv_stage<8, 2, 1, false>(r, ar, [&](int) { return T.s7; });
+            ks_reduce_all<8>(r, ar);
+            uint64_t *o = (c ? out1 : out0) + base + 2 * l;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<U64x2 *>(o + 128 * (kk >> 1) + 64 * (kk & 1)) = U64x2{r[2 * kk], r[2 * kk + 1]};
+            wsync();                                                 // exchange 1 read out before the other component's exchange 2
         }
-        wsync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pass C: inverse stages 6..0 (index bits 8..14) of the sums that pass B left half-way, then SEAL's division by the special
+// prime P with rounding, added into the ciphertext -- steps 3 and 4 of switch_key_inplace in one pass over the sums.
+// A workgroup of 512 threads owns the tile of columns [64 cb, 64 cb + 64) of ONE (ciphertext, component) and walks limbs:
+// first the special prime's (its t = (s_P + floor(P/2)) mod P stays in 16 registers per thread), then the data limbs
+// j0 .. j1-1, each: load the tile (pass A's OUTPUT order), three stages in registers, reduce, the exchange of pass A
+// backwards, four stages (the last folds N^-1 in, as SEAL does), canonical form, then per coefficient
+//     ct[J] += P^-1 * (s_J - (t mod q_J) + (floor(P/2) mod q_J))   (mod q_J).
+// Every twiddle is wave-uniform again (scalar operands).
+// ------------------------------------------------------------------------------------------------------------------
+struct KsLimbC {
+    uint64_t q, ratio0, ratio1;                 // modulus, floor(2^128 / q)
+    uint64_t half_mod, pinv, pinv_quot;         // floor(P/2) mod q, P^-1 mod q and its Shoup quotient (data limbs)
+    const TwU64 *itw;                           // inverse table of this modulus
+};
+
+template <class A, class Sync>
+PF_HD void ksc_inverse_tile(uint64_t (&r)[16], const A &ar, const TwU64 *__restrict__ itw, const uint64_t *__restrict__ src, int cb,
+                            uint64_t *lds, int tid, Sync &&sync) {
+    const int lane = tid & 63, w = wave_uniform(tid >> 6);
+    // registers = (g, r mod 8) with r div 8 = 2 w + g  (what pass A stored from)
+    const uint64_t *s0 = src + (size_t)w * 4096 + cb * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = s0[(size_t)k * 256];
+    const TwU64 *t4 = itw + 16 + 2 * w, *t5 = itw + 32 + 4 * w, *t6 = itw + 64 + 8 * w;
+    ks_inv_stage<16, 0, 0, true>(r, ar, [&](int g) { return const_load_tw(t6 + g); });
+    ks_inv_stage<16, 1, 1, true>(r, ar, [&](int g) { return const_load_tw(t5 + g); });
+    ks_inv_stage<16, 2, 2, true>(r, ar, [&](int g) { return const_load_tw(t4 + g); });
+    ks_reduce_all<16>(r, ar);
+    sync();                                                          // the previous limb's readers are done with the buffer
+    uint64_t *l1 = lds + w * 1024 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) l1[k * 64] = r[k];
+    sync();
+    const uint64_t *l0 = lds + w * 64 + lane;                       // registers = r div 8, wave = r mod 8
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = l0[k * 512];
+    ks_inv_stage<16, 0, 0, true>(r, ar, [&](int g) { return const_load_tw(itw + 8 + g); });
+    ks_inv_stage<16, 1, 1, true>(r, ar, [&](int g) { return const_load_tw(itw + 4 + g); });
+    ks_inv_stage<16, 2, 2, true>(r, ar, [&](int g) { return const_load_tw(itw + 2 + g); });
+    {   // last layer (index bit 14): N^-1 folded into both halves -- entry 0 is N^-1, entry 1 psi^-bitrev(1) * N^-1
+        const TwU64 tn = const_load_tw(itw), t1 = const_load_tw(itw + 1);
+#pragma unroll
+        for (int bb = 0; bb < 8; bb += 2) {
+            uint64_t vs[4];
+            TwU64 ts[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                vs[2 * i] = r[bb + i];
+                ar.template inv_split<3>(vs[2 * i], r[bb + i + 8], vs[2 * i + 1]);
+                ts[2 * i] = tn; ts[2 * i + 1] = t1;
+            }
+            ar.template mul_tw_n<4, true>(vs, ts);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { r[bb + i] = vs[2 * i]; r[bb + i + 8] = vs[2 * i + 1]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = ar.canon_small(r[k]);
+}
+
+// acc     half-inverted sums [2][K][N] of this ciphertext (pass B, INV); comp selects the component
+// ct      this ciphertext [2][D][N], coefficient form, updated in place
+// limb    callable: J -> KsLimbC
+template <class A, class LimbFn, class Sync>
+PF_HD void body_ksC(LimbFn &&limb, const uint64_t *__restrict__ acc, uint64_t *__restrict__ ct, int comp, int D, int K, int j0, int j1, int cb,
+                    uint64_t *lds, int tid, Sync &&sync) {
+    constexpr size_t N = KsGeo::N;
+    const int lane = tid & 63, w = wave_uniform(tid >> 6);
+    uint64_t t[16];
+    const KsLimbC lp = limb(K - 1);
+    const uint64_t P = lp.q, half = P >> 1;
+    {
+        const A ar{lp.q, 2 * lp.q, lp.ratio0, lp.ratio1};
+        ksc_inverse_tile(t, ar, lp.itw, acc + ((size_t)comp * K + (K - 1)) * N, cb, lds, tid, sync);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint64_t v = t[k] + half; t[k] = v >= P ? v - P : v; }
+    }
+    for (int J = j0; J < j1; ++J) {
+        const KsLimbC lm = limb(J);
+        const A ar{lm.q, 2 * lm.q, lm.ratio0, lm.ratio1};
+        uint64_t s[16];
+        ksc_inverse_tile(s, ar, lm.itw, acc + ((size_t)comp * K + J) * N, cb, lds, tid, sync);
+        uint64_t *c0 = ct + ((size_t)comp * D + J) * N + (size_t)w * 256 + cb * 64 + lane;       // registers = r div 8, wave = r mod 8
+        const uint64_t q = lm.q;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint64_t tj = t[k] - mulhi64(t[k], lm.ratio1) * q;                        // t mod q_J (barrett_reduce_64)
+            tj = tj >= q ? tj - q : tj;
+            uint64_t v = s[k] + (q - tj) + lm.half_mod;                                // < 3q
+            v = v >= 2 * q ? v - 2 * q : v;
+            v = v >= q ? v - q : v;
+            uint64_t x = v * lm.pinv - mulhi64(v, lm.pinv_quot) * q;                   // Shoup product, [0, 2q)
+            x = x >= q ? x - q : x;
+            x += c0[(size_t)k * 2048];
+            c0[(size_t)k * 2048] = x >= q ? x - q : x;
+        }
     }
 }
 

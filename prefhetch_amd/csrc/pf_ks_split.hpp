@@ -11,11 +11,15 @@ struct KsSplitArgs {
     const uint64_t *target;      // [nb][D][N] digits of this round's ciphertexts (coefficient form)
     uint64_t *x;                 // [nb][D][nJ][N] pass A's output
     const uint64_t *ksk;         // [D][2][K][N] key, NTT form
-    uint64_t *acc;               // [nb][2][K][N] accumulated products, NTT form (columns J0 .. J0 + nJ - 1 written)
+    uint64_t *acc;               // [nb][2][K][N] accumulated products (columns J0 .. J0 + nJ - 1 written): NTT form when ct is null, else
+                                 // after the first eight inverse stages (pass C finishes them)
     uint32_t D, K, nb, J0, nJ;
+    uint64_t *ct;                // [nb][2][D][N] ciphertexts of this round: non-null selects the fused tail (pass B inverts half-way,
+                                 // pass C finishes, divides by the special prime and adds into ct); null: NTT-form sums for k_ntt + k_ks_moddown
 };
 
 void launch_ksA(const KsSplitArgs &a, hipStream_t s);
 void launch_ksB(const KsSplitArgs &a, hipStream_t s);
+void launch_ksC(const KsSplitArgs &a, hipStream_t s);       // after every modulus of the round has been through passes A and B
 
 }  // namespace pf

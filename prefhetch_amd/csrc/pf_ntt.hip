@@ -35,7 +35,8 @@ struct pf_ctx {
     // tuning, read ONCE when the context is created (PF_KS_ROUND, PF_KS_JROUND, PF_KS_SPLIT; experiments only):
     size_t ks_round = 0;            // ciphertexts per round of the workspace (0: the default for this ring)
     uint32_t ks_jround = 0;         // two-pass path: key moduli per round (0: all)
-    int ks_split = 1;               // N = 32768, lazy 64-bit family: the two-pass digit transforms of ks_split.hpp
+    int ks_split = 1;               // N = 32768, lazy 64-bit family: the two-pass digit transforms of ks_split.hpp (PF_KS_SPLIT: 0 off,
+                                    // 1 with the inverse transforms and the division by P fused into passes B and C, 2 with k_ntt + k_ks_moddown)
     bool split_ok() const { return logn == 15 && arith() == 2 && ks_split; }
     size_t round_size(size_t B) const {
         const uint32_t K = L, D = K - 1;
@@ -486,10 +487,16 @@ pf_status pf_key_switch(pf_ctx *c, const uint64_t *target, const uint64_t *ksk, 
         KsArgs k{c->d_limbs, x, ksk, acc, ct + b0 * 2 * D * N, D, K, c->logn, (uint32_t)nb};
         if (split) {
             // 1 + 2. digit transforms in two passes, the second one accumulating the key products (ks_split.hpp)
+            const bool fused_tail = c->ks_split == 1;
+            KsSplitArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, ksk, acc, D, K, (uint32_t)nb, 0, 0, fused_tail ? ct + b0 * 2 * D * N : nullptr};
             for (uint32_t J0 = 0; J0 < K; J0 += nJ) {
-                KsSplitArgs a{c->d_limbs, c->d_tables, target + b0 * D * N, x, ksk, acc, D, K, (uint32_t)nb, J0, K - J0 < nJ ? K - J0 : nJ};
+                a.J0 = J0; a.nJ = K - J0 < nJ ? K - J0 : nJ;
                 launch_ksA(a, s);
                 launch_ksB(a, s);
+            }
+            if (fused_tail) {                                   // 3 + 4. rest of the inverse transforms + division by P, one pass
+                launch_ksC(a, s);
+                continue;
             }
         } else {
             // 1. digit NTTs: x[b][I][J] = NTT_{m_J}(target[b][I] mod m_J)

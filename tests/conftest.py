@@ -32,7 +32,7 @@ def _build_sim(name, extra):
     lib.pf_sim_range_violations.restype = C.c_ulonglong
     lib.pf_sim_psi.restype = C.c_uint64
     lib.pf_sim_psi.argtypes = [C.c_int, C.c_uint64]
-    lib.pf_sim_ks_split.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p]
+    lib.pf_sim_ks_split.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p]
     return lib
 
 

@@ -83,12 +83,22 @@ extern "C" uint64_t pf_sim_psi(int logn, uint64_t q) {
     return build_limb_tables(1u << logn, q, t, err) ? t.psi : 0;
 }
 
-// ---- the two-pass key switch at N = 32768 (prefhetch_amd/csrc/ks_split.hpp): pass A over every (digit, modulus) transform,
-// pass B over every (modulus, chunk), one OS thread per lane.  moduli[K], target [D][N], ksk [D][2][K][N] -> acc [2][K][N]
-// (NTT form, canonical): what k_ksA + k_ksB compute for one ciphertext.
+// ---- the two-pass key switch at N = 32768 (prefhetch_amd/csrc/ks_split.hpp), one OS thread per lane.  moduli[K] (special prime
+// last), target [D][N], ksk [D][2][K][N].  ct == nullptr: passes A + B<INV = false> -> acc [2][K][N] (NTT form, canonical): what
+// k_ksA + k_ksB<false> compute for one ciphertext.  ct != nullptr ([2][D][N], updated in place): passes A + B<INV = true> + C, the
+// whole of pf_key_switch's fused path (acc is scratch).
 #include "../../prefhetch_amd/csrc/ks_split.hpp"
 
-extern "C" int pf_sim_ks_split(int D, int K, const uint64_t *moduli, const uint64_t *target, const uint64_t *ksk, uint64_t *acc) {
+template <int T, class Body>
+static void run_threads(Body &&body) {
+    std::barrier bar(T);
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for (int tid = 0; tid < T; ++tid) th.emplace_back([&, tid] { auto sync = [&] { bar.arrive_and_wait(); }; body(tid, sync); });
+    for (auto &t : th) t.join();
+}
+
+extern "C" int pf_sim_ks_split(int D, int K, const uint64_t *moduli, const uint64_t *target, const uint64_t *ksk, uint64_t *acc, uint64_t *ct) {
     constexpr size_t N = KsGeo::N;
     std::vector<LimbTables> tabs(K);
     std::string err;
@@ -102,14 +112,9 @@ extern "C" int pf_sim_ks_split(int D, int K, const uint64_t *moduli, const uint6
             const ArithU64L ar{moduli[J], 2 * moduli[J], tabs[J].ratio0, tabs[J].ratio1};
             for (int cb = 0; cb < KsGeo::A_TILES; ++cb) {
                 std::vector<uint64_t> lds(KsGeo::A_LDS);
-                std::barrier bar(KsGeo::A_T);
-                std::vector<std::thread> th;
-                for (int tid = 0; tid < KsGeo::A_T; ++tid)
-                    th.emplace_back([&, tid] {
-                        auto sync = [&] { bar.arrive_and_wait(); };
-                        body_ksA<ArithU64L>(ar, tabs[J].fwd_u.data(), target + (size_t)I * N, x.data() + ((size_t)I * K + J) * N, cb, lds.data(), tid, sync);
-                    });
-                for (auto &t : th) t.join();
+                run_threads<KsGeo::A_T>([&](int tid, auto &sync) {
+                    body_ksA<ArithU64L>(ar, tabs[J].fwd_u.data(), target + (size_t)I * N, x.data() + ((size_t)I * K + J) * N, cb, lds.data(), tid, sync);
+                });
             }
         }
     for (int J = 0; J < K; ++J) {
@@ -117,16 +122,32 @@ extern "C" int pf_sim_ks_split(int D, int K, const uint64_t *moduli, const uint6
         for (int chunk = 0; chunk < KsGeo::B_CHUNKS; ++chunk) {
             std::vector<uint64_t> lds(KsGeo::B_LDS + 2);
             uint64_t *l16 = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
-            std::barrier bar(KsGeo::B_T);            // a barrier over the whole workgroup is a (stronger) wave barrier
-            std::vector<std::thread> th;
-            for (int tid = 0; tid < KsGeo::B_T; ++tid)
-                th.emplace_back([&, tid] {
-                    auto wsync = [&] { bar.arrive_and_wait(); };
-                    body_ksB<ArithU64L>(ar, tabs[J].fwd_u.data(), x.data() + (size_t)J * N, (size_t)K * N, ksk + (size_t)J * N, (size_t)K * N,
-                                        acc + (size_t)J * N, acc + ((size_t)K + J) * N, D, chunk, l16, tid, wsync);
-                });
-            for (auto &t : th) t.join();
+            run_threads<KsGeo::B_T>([&](int tid, auto &wsync) {          // a barrier over the whole workgroup is a (stronger) wave barrier
+                if (ct) body_ksB<ArithU64L, true>(ar, tabs[J].fwd_u.data(), tabs[J].inv_u.data(), x.data() + (size_t)J * N, (size_t)K * N, ksk + (size_t)J * N,
+                                                  (size_t)K * N, acc + (size_t)J * N, acc + ((size_t)K + J) * N, D, chunk, l16, tid, wsync);
+                else body_ksB<ArithU64L, false>(ar, tabs[J].fwd_u.data(), tabs[J].inv_u.data(), x.data() + (size_t)J * N, (size_t)K * N, ksk + (size_t)J * N,
+                                                (size_t)K * N, acc + (size_t)J * N, acc + ((size_t)K + J) * N, D, chunk, l16, tid, wsync);
+            });
         }
     }
+    if (!ct) return 0;
+    const uint64_t P = moduli[K - 1];
+    auto limb = [&](int J) {
+        KsLimbC c{moduli[J], tabs[J].ratio0, tabs[J].ratio1, 0, 0, 0, tabs[J].inv_u.data()};
+        if (J + 1 < K) {
+            c.half_mod = (P >> 1) % moduli[J];
+            c.pinv = h_powmod(P % moduli[J], moduli[J] - 2, moduli[J]);
+            c.pinv_quot = (uint64_t)((((u128_t)c.pinv) << 64) / moduli[J]);
+        }
+        return c;
+    };
+    for (int comp = 0; comp < 2; ++comp)
+        for (int j0 = 0; j0 < D; j0 += 2)                               // limb groups of two (the kernel's groups are larger)
+            for (int cb = 0; cb < KsGeo::A_TILES; ++cb) {
+                std::vector<uint64_t> lds(KsGeo::A_LDS);
+                run_threads<KsGeo::A_T>([&](int tid, auto &sync) {
+                    body_ksC<ArithU64L>(limb, acc, ct, comp, D, K, j0, j0 + 2 < D ? j0 + 2 : D, cb, lds.data(), tid, sync);
+                });
+            }
     return 0;
 }

@@ -103,7 +103,7 @@ def test_two_pass_key_switch_core_on_host_simulator(sim_lib, qs):
     ksk[0, 0, :, :4] = (np.array(qs, dtype=np.uint64) - 1)[:, None]
     acc = np.zeros((2, K, N), dtype=np.uint64)
     mods = np.array(qs, dtype=np.uint64)
-    assert sim_lib.pf_sim_ks_split(D, K, _p(mods), _p(target), _p(ksk), _p(acc)) == 0
+    assert sim_lib.pf_sim_ks_split(D, K, _p(mods), _p(target), _p(ksk), _p(acc), None) == 0
     for J, q in enumerate(qs):
         o = oracle.Oracle(N, [q])
         exp = [np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)]
@@ -113,6 +113,14 @@ def test_two_pass_key_switch_core_on_host_simulator(sim_lib, qs):
                 exp[c] = o.addsub(exp[c], o.dyadic_mul(xt, ksk[I, c, J]), 0)
         for c in range(2):
             assert (acc[c, J] == exp[c]).all(), (J, c)
+    # the whole fused path: pass B continues with the first eight INVERSE stages, pass C finishes them, divides by the special
+    # prime with rounding and adds into the ciphertext -- against the oracle's key switch (SEAL switch_key_inplace restated)
+    ct = np.stack([rng.integers(0, q, (2, N), dtype=np.uint64) for q in qs[:D]], axis=1)            # [2][D][N]
+    ct[0, 0, :3] = qs[0] - 1
+    exp_ct = oracle.Oracle(N, qs).key_switch(target.reshape(1, D, N), ksk, ct.reshape(1, 2, D, N)).reshape(2, D, N)
+    got = ct.copy()
+    assert sim_lib.pf_sim_ks_split(D, K, _p(mods), _p(target), _p(ksk), _p(acc), _p(got)) == 0
+    assert (got == exp_ct).all()
     assert sim_lib.pf_sim_range_violations() == 0
 
 
