@@ -230,7 +230,7 @@ def test_key_switch_parity(pf, N, qs, B):
 
 def test_config5_key_switch_full_ring(pf):
     """BASELINE config 5: N=32768, 15 data primes + special prime, key [15][2][16][32768] (126 MB): one ciphertext
-    against the oracle, and the same switch inside a batch of 20 (two workspace rounds) gives identical rows."""
+    against the oracle, and the same switch inside a batch of 40 (a full workspace round of 32 and a partial one of 8) gives identical rows."""
     N, qs = 32768, oracle.BFV_DEFAULT[32768]
     K, D = 16, 15
     rng = np.random.default_rng(20250801 + 5)
@@ -244,10 +244,10 @@ def test_config5_key_switch_full_ring(pf):
     d_ct = pf.to_device_u64(ct, _dev())
     c.key_switch_(pf.to_device_u64(target, _dev()), d_ksk, d_ct)
     assert (pf.to_host_u64(d_ct) == exp).all()
-    big_t = pf.to_device_u64(np.repeat(target, 20, axis=0), _dev())
-    big_c = pf.to_device_u64(np.repeat(ct, 20, axis=0), _dev())
+    big_t = pf.to_device_u64(np.repeat(target, 40, axis=0), _dev())
+    big_c = pf.to_device_u64(np.repeat(ct, 40, axis=0), _dev())
     c.key_switch_(big_t, d_ksk, big_c)
-    assert (pf.to_host_u64(big_c) == np.repeat(exp, 20, axis=0)).all()
+    assert (pf.to_host_u64(big_c) == np.repeat(exp, 40, axis=0)).all()
 
 
 def test_config5_key_switch_batch_256(pf):
