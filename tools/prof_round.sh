@@ -26,6 +26,12 @@ python3 tools/time_ivfpq.py > $O/${tag}_ivfpq.json 2> $O/${tag}_ivfpq.err
 cd /tmp && PF_CONFIG=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_ks -- python3 $R/tools/run_kernel.py keyswitch 2 256 > $O/${tag}_keyswitch.txt 2>&1
 cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_ks -name "*kernel_stats.csv" | head -1) $O/${tag}_keyswitch_kernel_stats.txt
 tail -3 $O/${tag}_keyswitch.txt
+# PMC passes of the key switch kernels (counters only, one pass each): vector-pipe busy = SQ_ACTIVE_INST_VALU x 4 / 1024 / (GRBM_GUI_ACTIVE / 8)
+for pass in "a:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+            "b:SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" \
+            "c:GRBM_GUI_ACTIVE" "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+  PF_CONFIG=5 bash tools/pmc_pass.sh ${tag}_ks_${pass%%:*} "${pass#*:}" keyswitch 1 64 >> $O/${tag}_pmc_keyswitch.txt 2>&1
+done
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_enc -- python3 $R/tools/run_kernel.py encround 5 1024 > $O/${tag}_encround.txt 2>&1
 cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_enc -name "*kernel_stats.csv" | head -1) $O/${tag}_encround_kernel_stats.txt
 tail -2 $O/${tag}_encround.txt
