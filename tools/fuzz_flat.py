@@ -13,8 +13,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for it in range(iters):
-    d = int(rng.choice([64, 128]))
-    nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 60000)]))
+    d = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128]))
+    nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 60000), rng.integers(60000, 400000)]))
     nq = int(rng.choice([rng.integers(1, 70), rng.integers(70, 300), rng.integers(300, 700)]))
     k = int(min(rng.choice([1, 7, 64, 200, 256, 257, 1024]), 1024))
     law = str(rng.choice(["int", "ties", "gauss", "mixed", "dups", "neg"]))
