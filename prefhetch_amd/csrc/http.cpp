@@ -7,6 +7,7 @@
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -22,7 +23,7 @@ namespace {
 bool send_all(int fd, const char *p, size_t n) {
     while (n) {
         const ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
-        if (w < 0) { if (errno == EINTR) continue; return false; }
+        if (w < 0) { if (errno == EINTR) continue; return false; }        // EAGAIN here = SO_SNDTIMEO expired: the peer is not reading
         p += w; n -= (size_t)w;
     }
     return true;
@@ -170,7 +171,7 @@ Parse try_parse(std::string &buf, Message &m, size_t max_body, bool &head_done) 
 // any other client waiting, and stop() is seen within one poll interval whatever the clients do.
 size_t HttpListener::serve(size_t max_requests) {
     using Clock = std::chrono::steady_clock;
-    constexpr int POLL_MS = 100, REQUEST_TIMEOUT_MS = 10000, IDLE_TIMEOUT_MS = 30000;
+    constexpr int POLL_MS = 100, REQUEST_TIMEOUT_MS = 10000, IDLE_TIMEOUT_MS = 30000, SEND_TIMEOUT_S = 10;
     constexpr size_t MAX_CONNECTIONS = 256;
     struct Conn { int fd; std::string buf; Clock::time_point last; bool continued = false; bool eof = false; };
     std::vector<Conn> conns;
@@ -256,6 +257,10 @@ size_t HttpListener::serve(size_t max_requests) {
             if (c >= 0) {
                 int one = 1;
                 ::setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                // a client that stops READING its (possibly multi-megabyte) response must not hold the one serving thread in send():
+                // the kernel gives up on a blocked send after SEND_TIMEOUT_S, send_all() fails, the connection is closed
+                timeval tv{SEND_TIMEOUT_S, 0};
+                ::setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
                 conns.push_back(Conn{c, std::string(), Clock::now()});
             }
         }

@@ -197,6 +197,14 @@ struct TileGeo {
     static_assert(THREADS == 256 && TN % ROWS_PER_IT == 0 && (TM % ROWS_PER_IT == 0 || TM < ROWS_PER_IT) && MI >= 1 && NJ >= 1, "unsupported tile geometry");
 };
 using GeoBatch = TileGeo<128, 128, 2, 2>;
+// the bf16 tiles (k_l2_tile16): 128 queries x PF_B16_TN base rows per workgroup.  128 columns: two 34 KiB column tiles + the survivor list =
+// 80 KiB, two workgroups per CU at a 256-register budget.  64 columns: 47 KiB, THREE workgroups per CU at 168 registers -- a wave does half
+// the matrix work per barrier, but a third wave per SIMD fills the pipe while the others wait (measured: DESIGN.md 4.3).
+#ifndef PF_B16_TN
+#define PF_B16_TN 128
+#endif
+using Geo16 = TileGeo<128, PF_B16_TN, PF_B16_TN == 64 ? 4 : 2, PF_B16_TN == 64 ? 1 : 2>;   // 64 columns: 4 x 1 waves of 32 x 64 (32 query-fragment registers, not 64)
+constexpr int B16_WG_PER_CU = PF_B16_TN == 64 ? 3 : 2;
 using GeoSmall64 = TileGeo<64, 256, 1, 4>;
 using GeoSmall32 = TileGeo<32, 256, 1, 4>;
 
@@ -609,8 +617,13 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 #ifndef PF_FLUSH_U
 #define PF_FLUSH_U 6
 #endif
+#if PF_B16_TN == 64
+#define PF_FLUSH_INLINE __forceinline__
+#else
+#define PF_FLUSH_INLINE __forceinline__
+#endif
 template <int D, int MT, int NJ>
-__device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
+__device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0) {
     (void)flush_no;
@@ -640,7 +653,7 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             for (int jj = 0; jj < NJ; ++jj) {
                 uint32_t m = surv[u][jj];
                 if (__ballot(m != 0) == 0) continue;                  // wave-uniform: nothing in this word anywhere in the wave
-                const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * 128 + wn + 32 * jj + (lane & 31));
+                const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * Geo16::TN + wn + 32 * jj + (lane & 31));
                 auto park = [&]() {                                   // highest set bit of m: one survivor
                     const int b = 31 - __builtin_clz(m);
                     m &= ~(1u << b);
@@ -671,41 +684,48 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             // query rows are only 128 different ones, so -- when the tile buffers are free: the walk's last flush -- they are
             // copied into LDS once, coalesced (row pitch D * 4 + 16 bytes: conflict-free 16-byte reads by 64 different rows).
             constexpr uint32_t XP = D * 4 + 16;
-            if (xstage) {
-                for (uint32_t i = tid; i < 128 * (D / 4); i += 256) {
-                    const uint32_t row = i / (D / 4), seg = i % (D / 4);
-                    *reinterpret_cast<float4 *>(xstage + row * XP + seg * 16) =
-                        reinterpret_cast<const float4 *>(p.xq + (q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)D)[seg];
-                }
-            }
+            // the tile buffers hold all 128 staged rows, or (64-column tiles) half of them: then the list is worked off in two halves by row
+            constexpr uint32_t XROWS = 2u * Geo16::TN * (D + AUX16) * 2u >= 128u * XP ? 128u : 64u;
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
                 pd.rcnt[tid] = 0;
             }
-            __syncthreads();
-            for (uint32_t e = tid; e < n; e += 256) {
-                const uint32_t row = pd.loc[e], id = pd.id[e], pos = atomicAdd(&pd.rbase[row], 1u);
-                if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
-                const float4 *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
-                float acc = 0.f;
+            for (uint32_t r0 = 0; r0 < (xstage ? 128u : XROWS); r0 += XROWS) {        // (without staging: one round over everything)
                 if (xstage) {
-                    const float4 *x = reinterpret_cast<const float4 *>(xstage + row * XP);
-#pragma unroll 8
-                    for (int t = 0; t < D / 4; ++t) {
-                        const float4 a = x[t], b = y[t];
-                        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
-                    }
-                } else {
-                    const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D);
-#pragma unroll 4
-                    for (int t = 0; t < D / 4; ++t) {
-                        const float4 a = x[t], b = y[t];
-                        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                    if (r0) __syncthreads();                              // the first half's readers are done
+                    for (uint32_t i = tid; i < XROWS * (D / 4); i += 256) {
+                        const uint32_t row = r0 + i / (D / 4), seg = i % (D / 4);
+                        *reinterpret_cast<float4 *>(xstage + (row - r0) * XP + seg * 16) =
+                            reinterpret_cast<const float4 *>(p.xq + (q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)D)[seg];
                     }
                 }
-                const float dist = fmaf(-2.f, acc, sA[2 * row] + p.bn[id]);
-                p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+                __syncthreads();
+                for (uint32_t e = tid; e < n; e += 256) {
+                    const uint32_t row = pd.loc[e], id = pd.id[e];
+                    if (xstage && (row < r0 || row >= r0 + XROWS)) continue;
+                    const uint32_t pos = atomicAdd(&pd.rbase[row], 1u);
+                    if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
+                    const float4 *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
+                    float acc = 0.f;
+                    if (xstage) {
+                        const float4 *x = reinterpret_cast<const float4 *>(xstage + (row - r0) * XP);
+#pragma unroll 8
+                        for (int t = 0; t < D / 4; ++t) {
+                            const float4 a = x[t], b = y[t];
+                            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                        }
+                    } else {
+                        const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D);
+#pragma unroll 4
+                        for (int t = 0; t < D / 4; ++t) {
+                            const float4 a = x[t], b = y[t];
+                            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                        }
+                    }
+                    const float dist = fmaf(-2.f, acc, sA[2 * row] + p.bn[id]);
+                    p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+                }
             }
             __syncthreads();
             if (tid == 0) pd.n = 0;
@@ -781,7 +801,7 @@ __device__ __forceinline__ void pend16_flush(const TileArgs &p, Pend16 &pd, cons
 template <class GEO>
 __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::NJ], const bool (&col_ok)[GEO::NJ], uint32_t (&surv)[GEO::NJ]) {
     constexpr int MI = GEO::MI, NJ = GEO::NJ;
-    static_assert(MI * 16 == 32, "one verdict word per column block: 32 accumulator rows per lane");
+    static_assert(MI * 16 == 32 || MI * 16 == 16, "one verdict word per column block: 32 (or 16) accumulator rows per lane");
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         uint32_t fail = 0;
@@ -789,6 +809,7 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(acc[i][jj][r]), 31);
+        if constexpr (MI == 1) fail = (fail << 16) | 0xFFFFu;           // 16 rows per lane: they sit in the word's upper half, the lower half never passes
         surv[jj] = col_ok[jj] ? ~fail : 0u;                              // columns past the end of the chunk re-read rows of the next one
     }
 }
@@ -800,12 +821,12 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
 template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
-__global__ void __launch_bounds__(256, 2) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
-    using GEO = GeoBatch;
+__global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
+    using GEO = Geo16;
     constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
     constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
-    static_assert(PITCH % 32 == 16 && TN == 128 && TM == 128, "odd row pitch in 16-byte units; 128 x 128 tiles");
+    static_assert(PITCH % 32 == 16 && (TN == 128 || TN == 64) && TM == 128, "odd row pitch in 16-byte units; 128 x 128 or 128 x 64 tiles");
     __shared__ __align__(16) char smem[SMEM];
     __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
     __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
@@ -1815,7 +1836,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = b16 ? 2 : nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
-    const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = geo == 2 ? 128 : 256;
+    const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = b16 ? (size_t)Geo16::TN : geo == 2 ? 128 : 256;
+    const size_t slots = b16 ? f->num_cus * (size_t)B16_WG_PER_CU : f->wg_slots;       // workgroups of the tile kernel resident at once
     t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
@@ -1826,7 +1848,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             // tiles; 16 k columns ran as 2 x 1 tile, 213 k as 3.25 rounds of 8.  Measured over the cap: 8 0.555, 16 0.537, 32 0.520,
             // 64 0.514, 128 0.510 ms per search -- most chunks are then one round of workgroups that walk their whole share.)
             const size_t group_cap = f->group_cap;
-            const size_t per_round = 2 * f->num_cus / t.n_qtiles ? 2 * f->num_cus / t.n_qtiles : 1;       // column groups of one round
+            const size_t per_round = slots / t.n_qtiles ? slots / t.n_qtiles : 1;       // column groups of one round
             const size_t rounds = (nct + per_round * group_cap - 1) / (per_round * group_cap);
             size_t group = (nct + per_round * rounds - 1) / (per_round * rounds);
             group = group < 1 ? 1 : group;
@@ -1894,7 +1916,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             chunk = chunk_no >= n_chunks || end >= (double)f->nb ? f->nb - pos : ((size_t)end - pos) / 1024 * 1024;
             if (chunk < 4096) chunk = 4096;
             // whole rounds of resident workgroups: the short early chunks take as long as their rounds, however full the last one is
-            const size_t round_cols = (f->wg_slots / t.n_qtiles ? f->wg_slots / t.n_qtiles : 1) * TN;
+            const size_t round_cols = (slots / t.n_qtiles ? slots / t.n_qtiles : 1) * TN;
             if (chunk > round_cols && chunk < f->nb - pos) chunk = (chunk + round_cols / 2) / round_cols * round_cols;
             if (chunk > f->nb - pos || f->nb - pos - chunk < 4096) chunk = f->nb - pos;
         } else {
