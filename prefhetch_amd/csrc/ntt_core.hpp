@@ -939,14 +939,16 @@ PF_HD void xchg_and_load(typename A::V (&r)[G::R], PassTw<G, A, RD> &t, const ty
     if constexpr (!early) t.template load<fwd, HEAD>(tw, tid);
 }
 
-template <class G, class A, bool HEAD_EARLY = false, class Sync>
+struct NoHook { PF_HD void operator()() const {} };
+// `before_last` runs after the last exchange, ahead of the last pass's arithmetic (the fused kernel requests its plaintext there)
+template <class G, class A, bool HEAD_EARLY = false, class Sync, class Hook = NoHook>
 PF_HD void fwd_all(typename A::V (&r)[G::R], const A &ar, const typename A::Tw *__restrict__ tw,
-                   typename A::V *lds, int tid, Sync &&sync) {
+                   typename A::V *lds, int tid, Sync &&sync, Hook &&before_last = Hook{}) {
     { PassTw<G, A, 0> t0; t0.template load<true>(tw, tid); fwd_pass<G, A, 0>(r, ar, t0); }
     PF_STAMP(2);
     if constexpr (G::P >= 2) { PassTw<G, A, 1> t; xchg_and_load<G, A, 0, 1, HEAD_EARLY>(r, t, tw, lds, tid, sync); PF_STAMP(3); fwd_pass<G, A, 1>(r, ar, t); }
     PF_STAMP(4);
-    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2, HEAD_EARLY>(r, t, tw, lds, tid, sync); PF_STAMP(5); fwd_pass<G, A, 2>(r, ar, t); }
+    if constexpr (G::P >= 3) { PassTw<G, A, 2> t; xchg_and_load<G, A, 1, 2, HEAD_EARLY>(r, t, tw, lds, tid, sync); PF_STAMP(5); if constexpr (G::P == 3) before_last(); fwd_pass<G, A, 2>(r, ar, t); }
     PF_STAMP(6);
     if constexpr (G::P >= 4) { PassTw<G, A, 3> t; xchg_and_load<G, A, 2, 3, HEAD_EARLY>(r, t, tw, lds, tid, sync); fwd_pass<G, A, 3>(r, ar, t); }
 }
@@ -1020,6 +1022,19 @@ PF_HD void load_last(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
     }
 }
 
+// registers [K0, K1) only (K0, K1 even): the fused kernel requests part of its plaintext ahead of the last forward pass
+template <class G, class A, int K0, int K1>
+PF_HD void load_last_part(typename A::V (&r)[G::R], const uint64_t *src, int tid) {
+    constexpr int L = G::LAST;
+    static_assert(G::nl(L) >= 1 && K0 % 2 == 0 && K1 % 2 == 0, "16-byte accesses");
+    const int b = G::base(L, tid);
+#pragma unroll
+    for (int k = K0; k < K1; k += 2) {
+        const U64x2 v = *reinterpret_cast<const U64x2 *>(src + G::koff(L, k) + b);
+        r[k] = A::from_u64(v.x); r[k + 1] = A::from_u64(v.y);
+    }
+}
+
 template <class G>
 PF_HD void store_last(const uint64_t (&o)[G::R], uint64_t *dst, int tid) {
     constexpr int L = G::LAST, NL = G::nl(L);
@@ -1081,6 +1096,12 @@ PF_HD void store_last_staged(const uint64_t (&o)[G::R], uint64_t *dst, int tid, 
 // Kernel bodies
 // ------------------------------------------------------------------------------------------------
 enum : int { CTPT_ACCUMULATE = 1, CTPT_IN_NTT = 2, CTPT_OUT_NTT = 4 };
+#ifndef PF_CTPT_TL_EARLY
+#define PF_CTPT_TL_EARLY 0
+#endif
+#ifndef PF_CTPT_PT_EARLY
+#define PF_CTPT_PT_EARLY 8      // plaintext registers requested before the last forward pass (0: all of it after the pass; measured at N = 8192: 8 -> -2.2 %, 16 spills)
+#endif
 
 // forward NTT of one limb-polynomial: natural-order coefficients in, bit-reversed evaluations out
 template <class G, class A, class Sync>
@@ -1143,12 +1164,27 @@ PF_HD void body_ctpt(const A &ar, const typename A::Tw *__restrict__ tw, const t
         PF_STAMP(0);
         load_l0<G, A>(r, ct, tid);
         PF_STAMP(1);
+#if PF_CTPT_PT_EARLY
+        // the plaintext limb is read in the layout the forward transform ends in (lane-contiguous from HBM), and requested BEFORE the
+        // last pass's three stages: its trip to memory runs under them instead of in front of the dyadic product
+        if constexpr (G::P == 3 && A::PREFETCH_TW && G::nl(G::LAST) >= 1 && G::LOGN <= 13) {      // (N >= 16384: the FP64 kernels spill already)
+            constexpr int EARLY = PF_CTPT_PT_EARLY < G::R ? PF_CTPT_PT_EARLY : G::R;      // registers of the plaintext requested early
+            fwd_all<G, A>(r, ar, tw, lds, tid, sync, [&] { load_last_part<G, A, 0, EARLY>(pv, pt, tid); });
+            load_last_part<G, A, EARLY, G::R>(pv, pt, tid);
+        } else { fwd_all<G, A>(r, ar, tw, lds, tid, sync); load_last<G, A>(pv, pt, tid); }
+#else
         fwd_all<G, A>(r, ar, tw, lds, tid, sync);
         // the plaintext limb is read in the layout the forward transform ended in: lane-contiguous from HBM
         load_last<G, A>(pv, pt, tid);
+#endif
         PF_STAMP(7);
+#if PF_CTPT_TL_EARLY
+        if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);      // the first inverse pass's twiddles travel under the dyadic product
+        dyadic_all<G, A, true>(r, pv, ar);
+#else
         dyadic_all<G, A, true>(r, pv, ar);
         if constexpr (!(FLAGS & CTPT_OUT_NTT)) tl.load(itw, tid);
+#endif
         PF_STAMP(8);
     }
     if constexpr (FLAGS & CTPT_OUT_NTT) {
