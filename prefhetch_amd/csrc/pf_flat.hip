@@ -608,6 +608,8 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 #define PF_FLSTAMP(k) do { } while (0)
 #endif
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (defined with the selection kernels below)
+
 // The verdict words of MT tiles (surv[u][jj]: tile ct_base + u, column block jj; bit 31 - s = accumulator row s of this lane)
 // are decoded here, once per MT tiles, by the lane that owns them: each survivor takes a slot of the list and its index
 // within its query row (LDS atomics), a row with survivors reserves its range of the candidate list with ONE global atomic,
@@ -643,26 +645,61 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
     // memory per walk instead of one per MT tiles (the flushes were 35 % of the tile kernels' time: profiles/r03_flat_ablation.txt).
     for (;;) {
         PF_FLSTAMP(1);
-        uint32_t slot = left ? atomicAdd(&pd.n, left) : 0u;
+        // slots: ONE returning LDS atomic per wave (a prefix sum over the lanes' counts), not one per lane with survivors
+        const uint32_t incl = wave_incl_scan(left);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t slot = 0;
+        if (tot) {                                                       // wave-uniform
+            if (lane == 0) slot = atomicAdd(&pd.n, tot);
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot) + incl - left;
+        }
         uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
         take = left < take ? left : take;
         left -= take;
+        auto park_at = [&](uint32_t w, int b) {                          // survivor = bit b of verdict word w = u * NJ + jj
+            const uint32_t u = w / NJ, jj = w % NJ;
+            const int s = 31 - b, r = s & 15;
+            const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+            pd.id[slot] = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * Geo16::TN + wn + 32 * jj + (lane & 31));
+            pd.loc[slot] = (uint8_t)lrow;
+            atomicAdd(&pd.rcnt[lrow], 1u);                              // no return value: the position inside the row is drawn when the key is written
+            ++slot;
+        };
+        if (!tot) {
+            // nothing in this wave
+        } else if (__ballot(take > 2 || left != 0) == 0) {
+            // Sparse case (the long late chunks: ~20 survivors per wave and call): no lane holds more than two.  The words are
+            // scanned WITHOUT branches into at most two (word, bit) pairs per lane, then the pairs are parked -- the word-by-word
+            // loop below costs a vector-compare -> scalar-branch round trip per word (6 000 cycles per call: phase stamps)
+            uint32_t e0 = ~0u, e1 = ~0u;
+#pragma unroll
+            for (int u = 0; u < MT; ++u)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const uint32_t m = surv[u][jj], w = (uint32_t)(u * NJ + jj);
+                    const int b = 31 - __builtin_clz(m | 1u);            // (m | 1: defined for m = 0, unused then)
+                    const uint32_t m2 = m & ~(1u << b);
+                    const int b2 = 31 - __builtin_clz(m2 | 1u);
+                    const uint32_t pk = (w << 5) | (uint32_t)b, pk2 = (w << 5) | (uint32_t)b2;
+                    e1 = (m != 0 && e0 != ~0u) ? pk : e1;
+                    e0 = (m != 0 && e0 == ~0u) ? pk : e0;
+                    e1 = m2 != 0 ? pk2 : e1;
+                    surv[u][jj] = 0;
+                }
+            if (e0 != ~0u) park_at(e0 >> 5, (int)(e0 & 31u));
+            if (e1 != ~0u) park_at(e1 >> 5, (int)(e1 & 31u));
+        } else {
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 uint32_t m = surv[u][jj];
                 if (__ballot(m != 0) == 0) continue;                  // wave-uniform: nothing in this word anywhere in the wave
-                const uint32_t id = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * Geo16::TN + wn + 32 * jj + (lane & 31));
                 auto park = [&]() {                                   // highest set bit of m: one survivor
                     const int b = 31 - __builtin_clz(m);
                     m &= ~(1u << b);
-                    const int s = 31 - b, r = s & 15;
-                    const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                    pd.id[slot] = id;
-                    pd.loc[slot] = (uint8_t)lrow;
-                    atomicAdd(&pd.rcnt[lrow], 1u);                      // no return value: the position inside the row is drawn when the key is written
-                    ++slot; --take;
+                    park_at((uint32_t)(u * NJ + jj), b);
+                    --take;
                 };
                 // a lane rarely holds more than one bit of a word: the first one without a loop (a loop iteration costs a vector
                 // compare -> exec round trip; sixteen word loops were 5 400 of a flush's 15 000 cycles), the rest -- if any lane of
@@ -671,6 +708,7 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 if (__ballot(m && take)) while (m && take) park();
                 surv[u][jj] = m;
             }
+        }
         PF_FLSTAMP(2);
         const bool any_left = __syncthreads_or(left != 0) != 0;          // (the barrier: everything parked is visible)
         PF_FLSTAMP(3);
@@ -817,6 +855,12 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #ifndef PF_FLAT_MT
 #define PF_FLAT_MT 8
 #endif
+#ifndef PF_FLAT_STAGGER
+#define PF_FLAT_STAGGER 0       // 1: workgroups with bit 5 of their per-XCD index set start late; 2: odd ones; 0: none
+#endif
+#ifndef PF_FLAT_STAGGER_SLEEP
+#define PF_FLAT_STAGGER_SLEEP 3
+#endif
 #ifndef PF_DMA_SPREAD
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
@@ -889,6 +933,17 @@ __global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, ui
             bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
+    // Stagger.  The two workgroups that share a CU run the same loop with one barrier per tile and settle into LOCKSTEP: both in their
+    // 36 matrix instructions at once (each then sees ~74 cycles per instruction: phase stamps, profiles/r03_flat_stagger.txt), both in
+    // their sweep / barrier / parking at once -- the matrix pipe idles through every such stretch (54 % busy).  Half of the workgroups
+    // start half a tile period late, so that one partner's matrix work runs beside the other's everything-else.  Which workgroups
+    // share a CU is the dispatcher's business: the choice below (every other group of 32 per XCD) is for speed only.
+#if PF_FLAT_STAGGER
+    if (FILTER && (PF_FLAT_STAGGER == 1 ? ((j >> 5) & 1u) : (j & 1u))) {
+#pragma unroll 1
+        for (int i = 0; i < PF_FLAT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(8);            // ~512 cycles each
+    }
+#endif
     // the first tile is requested BEFORE the query fragments and row thresholds are loaded: one round trip to memory for the
     // prologue of a walk instead of two (a walk is 8 tiles of ~2 us; the serialised prologue was ~4 us of it)
     stage_b(ct0, sB16_0);
