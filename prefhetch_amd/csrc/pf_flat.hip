@@ -855,12 +855,6 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #ifndef PF_FLAT_MT
 #define PF_FLAT_MT 8
 #endif
-#ifndef PF_FLAT_STAGGER
-#define PF_FLAT_STAGGER 0       // 1: workgroups with bit 5 of their per-XCD index set start late; 2: odd ones; 0: none
-#endif
-#ifndef PF_FLAT_STAGGER_SLEEP
-#define PF_FLAT_STAGGER_SLEEP 3
-#endif
 #ifndef PF_DMA_SPREAD
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
@@ -933,17 +927,6 @@ __global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, ui
             bn_next[jj] = c < p.nb_count ? p.bn[p.nb_first + c] : 0.f;
         }
     };
-    // Stagger.  The two workgroups that share a CU run the same loop with one barrier per tile and settle into LOCKSTEP: both in their
-    // 36 matrix instructions at once (each then sees ~74 cycles per instruction: phase stamps, profiles/r03_flat_stagger.txt), both in
-    // their sweep / barrier / parking at once -- the matrix pipe idles through every such stretch (54 % busy).  Half of the workgroups
-    // start half a tile period late, so that one partner's matrix work runs beside the other's everything-else.  Which workgroups
-    // share a CU is the dispatcher's business: the choice below (every other group of 32 per XCD) is for speed only.
-#if PF_FLAT_STAGGER
-    if (FILTER && (PF_FLAT_STAGGER == 1 ? ((j >> 5) & 1u) : (j & 1u))) {
-#pragma unroll 1
-        for (int i = 0; i < PF_FLAT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(8);            // ~512 cycles each
-    }
-#endif
     // the first tile is requested BEFORE the query fragments and row thresholds are loaded: one round trip to memory for the
     // prologue of a walk instead of two (a walk is 8 tiles of ~2 us; the serialised prologue was ~4 us of it)
     stage_b(ct0, sB16_0);
