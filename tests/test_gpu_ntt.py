@@ -210,6 +210,8 @@ KS_CONFIGS = [  # (N, key moduli: data primes + special prime last, batch)
     (4096, oracle.BFV_DEFAULT[4096], 5),                        # 36/36-bit data + 37-bit special: exact-FP64 NTTs
     (8192, oracle.BFV_DEFAULT[8192], 18),                       # 4 data + special, more than one workspace round
     (32768, oracle.BFV_DEFAULT[32768][:3] + oracle.BFV_DEFAULT[32768][-1:], 2),
+    (32768, oracle.BFV_DEFAULT[32768][3:4] + oracle.BFV_DEFAULT[32768][-1:], 3),          # one digit: the smallest two-pass key switch
+    (32768, oracle.BFV_DEFAULT[32768][:5] + oracle.BFV_DEFAULT[32768][-1:], 2),           # five digits: uneven limb groups in pass C
 ]
 
 
