@@ -569,10 +569,13 @@ def main():
 
     cfg2 = cfg5 = None
     if extras:
-        cfg2 = config2_block(pf, dev)
+        try:
+            cfg2 = config2_block(pf, dev)
+        except Exception as ex:                                    # never lose the headline line to an extra
+            cfg2 = {"error": repr(ex)}
         try:
             cfg5 = config5_block(pf, dev)
-        except Exception as ex:                                    # never lose the headline line to an extra
+        except Exception as ex:
             cfg5 = {"error": repr(ex)}
         torch.cuda.empty_cache()
 
