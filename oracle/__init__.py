@@ -101,7 +101,7 @@ class Oracle:
             raise ValueError("oracle: invalid N/moduli (need prime q < 2^61 with q = 1 mod 2N)")
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # (module globals are gone when the interpreter is shutting down)
             lib().pfo_ctx_destroy(self._h)
             self._h = None
 
