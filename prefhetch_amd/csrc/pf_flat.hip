@@ -98,17 +98,17 @@ constexpr uint32_t AUX16 = 8;                   // 16-bit words a base row of th
 
 // row norms (fp32 fma chain in index order) + 16-bit image + eligibility.  A workgroup of 64 threads takes ROWS rows: the rows
 // are read coalesced (and converted / checked) by all lanes into LDS, then lane r chains row r's norm out of LDS (row pitch
-// d + 1 floats: conflict-free).  d <= PREP_MAX_D; wider rows take the one-thread-per-row kernel below.  ROWS = 64 for the
+// d + 1 floats: conflict-free).  d <= MAXD <= PREP_MAX_D; wider rows take the one-thread-per-row kernel below.  ROWS = 64 (32) for the
 // base (millions of rows), 4 for a batch of queries (1024 rows in 64 rows per workgroup were 16 workgroups and 37 us).
 // The image has `pitch16` 16-bit words per row.  With `aux` (the base), words d .. d+7 of a row hold the column's half of the
 // threshold term the bf16 tiles feed to the matrix pipe as a ninth k-step: (-b0, -b1, -b2, 1, 1, 1, 0, 0), b0 + b1 + b2 =
 // |y|^2 / 2 exactly (bf16_split3); the query's half is built by the tile kernel (k_l2_tile16).
-constexpr uint32_t PREP_MAX_D = 128;
-template <uint32_t ROWS>
+constexpr uint32_t PREP_MAX_D = 256;                            // rows up to 128 values: 64 per workgroup; up to 256: 32 (the staging tile stays at 33 KiB)
+template <uint32_t ROWS, uint32_t MAXD>
 __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
                                                   uint16_t *__restrict__ x16, uint32_t pitch16, bool aux, uint32_t *__restrict__ inexact,
                                                   uint32_t rows_per_flag) {
-    __shared__ float tile[ROWS * (PREP_MAX_D + 1)];
+    __shared__ float tile[ROWS * (MAXD + 1)];
     const size_t r0 = (size_t)blockIdx.x * ROWS;
     const uint32_t rows = (uint32_t)(n - r0 < ROWS ? n - r0 : ROWS), total = rows * d, lane = threadIdx.x;
     const float *src = x + r0 * d;
@@ -205,6 +205,11 @@ using GeoBatch = TileGeo<128, 128, 2, 2>;
 #endif
 using Geo16 = TileGeo<128, PF_B16_TN, PF_B16_TN == 64 ? 4 : 2, PF_B16_TN == 64 ? 1 : 2>;   // 64 columns: 4 x 1 waves of 32 x 64 (32 query-fragment registers, not 64)
 constexpr int B16_WG_PER_CU = PF_B16_TN == 64 ? 3 : 2;
+// rows of 144 .. 256 values: the query fragments of a 64-row wave tile would fill 128 registers, so a wave takes 32 query rows x 64 columns
+// (64 fragment registers at d = 256) and the column tile is 64 rows (2 x 33 KiB at d = 256: still two workgroups per CU)
+using Geo16W = TileGeo<128, 64, 4, 1>;
+template <int D, bool WIDE = (D > 128)> struct Geo16Of { using type = Geo16; static constexpr int WG_PER_CU = B16_WG_PER_CU; };
+template <int D> struct Geo16Of<D, true> { using type = Geo16W; static constexpr int WG_PER_CU = 2; };
 using GeoSmall64 = TileGeo<64, 256, 1, 4>;
 using GeoSmall32 = TileGeo<32, 256, 1, 4>;
 
@@ -624,14 +629,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (define
 #else
 #define PF_FLUSH_INLINE __forceinline__
 #endif
-template <int D, int MT, int NJ>
+template <int D, int MT, int NJ, int TN>
 __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     // lanes per survivor: LU = D / 8 of them hold 16 bytes of both rows each, rounded up to a power of two (L) for the DPP sum
-    constexpr uint32_t LU = D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : 16, G = 256 / L;         // G survivors per pass
+    constexpr uint32_t LU = D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : LU <= 16 ? 16 : 32, G = 256 / L;         // G survivors per pass
     const int lane = tid & 63;
     uint32_t left = 0;
 #pragma unroll
@@ -660,7 +665,7 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             const uint32_t u = w / NJ, jj = w % NJ;
             const int s = 31 - b, r = s & 15;
             const uint32_t lrow = (uint32_t)(wm + 2 * (s & 16) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-            pd.id[slot] = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * Geo16::TN + wn + 32 * jj + (lane & 31));
+            pd.id[slot] = (uint32_t)(p.nb_first + (size_t)(ct_base + u) * TN + wn + 32 * jj + (lane & 31));
             pd.loc[slot] = (uint8_t)lrow;
             atomicAdd(&pd.rcnt[lrow], 1u);                              // no return value: the position inside the row is drawn when the key is written
             ++slot;
@@ -723,7 +728,8 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             // copied into LDS once, coalesced (row pitch D * 4 + 16 bytes: conflict-free 16-byte reads by 64 different rows).
             constexpr uint32_t XP = D * 4 + 16;
             // the tile buffers hold all 128 staged rows, or (64-column tiles) half of them: then the list is worked off in two halves by row
-            constexpr uint32_t XROWS = 2u * Geo16::TN * (D + AUX16) * 2u >= 128u * XP ? 128u : 64u;
+            constexpr uint32_t XROWS = 2u * TN * (D + AUX16) * 2u >= 128u * XP ? 128u : 64u;
+            static_assert(2u * TN * (D + AUX16) * 2u >= XROWS * XP, "the staged query rows fit the two tile buffers");
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
@@ -817,7 +823,8 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
                 if constexpr (L >= 4) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
                 if constexpr (L >= 8) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
-                if constexpr (L == 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
+                if constexpr (L >= 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
+                if constexpr (L == 32) s += __shfl_xor(s, 16);          // the neighbouring row of 16 lanes (integers: any order of additions is exact)
                 if (pos[u] < p.cap) {                                 // (~0 for idle lanes and groups)
                     const uint32_t row = loc[u];
                     const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
@@ -858,9 +865,9 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #ifndef PF_DMA_SPREAD
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
-template <bool FILTER, int D>                                       // D = row length (64 or 128): every loop below is compile-time
-__global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
-    using GEO = Geo16;
+template <bool FILTER, int D>                                       // D = row length (a multiple of 16 up to 256): every loop below is compile-time
+__global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
+    using GEO = typename Geo16Of<D>::type;
     constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
     constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
@@ -963,6 +970,10 @@ __global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, ui
             const float rq = stage[3 * TM + arow];                                // (|x|^2 - tau) / 2; +inf for rows past nq
             const float big = fabsf(rq) * 0x1p-14f;
             float margin = fabsf(rq) <= 0x1p22f ? 0.f : (big > 256.f ? big : 256.f);
+            // exact operands in rows beyond 128 values: x.y is still exact (integers up to 2^24), but the threshold step adds half-integers to
+            // it at magnitudes up to 2^26, where fp32 has none -- its handful of additions can be off by a few units in 2^26: 2^-20 of the
+            // bound (|x|^2 + max |y|^2) / 2 + |R| on every partial sum covers them
+            if (D > 128 && !approx) margin += 0x1p-20f * (0.5f * (stage[2 * arow] + p.bn_max) + fabsf(rq));
             // inexact operands: |bf16(x).bf16(y) - x.y| <= (2^-7 + 2^-16) sum |x_i y_i| <= (2^-8 + 2^-17) (|x|^2 + |y|^2); the fp32
             // chain that decides in the end, the accumulation inside the matrix pipe and the pieces of the thresholds add a few
             // 2^-24 of the same sum (about 4e-5 (|x|^2 + |y|^2) in all): 1.05 x 2^-8 covers them.
@@ -1099,7 +1110,7 @@ __global__ void __launch_bounds__(256, B16_WG_PER_CU) k_l2_tile16(TileArgs p, ui
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
-                pend16_flush<D, MT, NJ>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
@@ -1763,9 +1774,9 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     if (e == hipSuccess && nb) {
         // row norms; and, where the shape allows the bf16 loop, the 16-bit image with its value-by-value exactness check
         uint32_t *flag = nullptr;
-        // every row length that is a multiple of the matrix instruction's k-step up to 128 (k_rows_prep stages whole rows in LDS
-        // up to PREP_MAX_D = 128; the query fragments of a 128-row tile fill 64 registers at d = 128: twice that does not fit)
-        const bool try16 = d % 16 == 0 && d <= 128 && getenv("PF_FLAT_NO_BF16") == nullptr;
+        // every row length that is a multiple of the matrix instruction's k-step up to 256 (k_rows_prep stages whole rows in LDS
+        // up to PREP_MAX_D; beyond 128 values the tiles are 128 x 64: Geo16W)
+        const bool try16 = d % 16 == 0 && d <= 256 && getenv("PF_FLAT_NO_BF16") == nullptr;
         // image rows carry AUX16 threshold words behind their d values; one tile of zero rows pads the end (k_l2_tile16 copies whole tiles)
         const size_t bytes16 = (nb + 128) * (size_t)(d + AUX16) * 2;
         if (try16 && (hipMalloc((void **)&f->xb16, bytes16) != hipSuccess || hipMemset(f->xb16, 0, bytes16) != hipSuccess ||
@@ -1774,7 +1785,8 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             if (f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }
             if (flag) { (void)hipFree(flag); flag = nullptr; }
         }
-        if (d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep<64>, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
+        if (d <= 128) hipLaunchKernelGGL((k_rows_prep<64, 128>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
+        else if (d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<32, PREP_MAX_D>), dim3((unsigned)((nb + 31) / 32)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
         else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1861,7 +1873,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
     if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
-    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL(k_rows_prep<4>, dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, f->d,
+    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, f->d,
                                                false, b16 ? qbad : nullptr, 128u);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
@@ -1874,8 +1886,9 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = b16 ? 2 : nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
-    const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = b16 ? (size_t)Geo16::TN : geo == 2 ? 128 : 256;
-    const size_t slots = b16 ? f->num_cus * (size_t)B16_WG_PER_CU : f->wg_slots;       // workgroups of the tile kernel resident at once
+    const bool wide16 = b16 && f->d > 128;                                             // Geo16W
+    const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = b16 ? (size_t)(wide16 ? Geo16W::TN : Geo16::TN) : geo == 2 ? 128 : 256;
+    const size_t slots = b16 ? f->num_cus * (size_t)(wide16 ? 2 : B16_WG_PER_CU) : f->wg_slots;       // workgroups of the tile kernel resident at once
     t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
     auto launch_tile = [&](bool filter, size_t cols) {
         const size_t nct = (cols + TN - 1) / TN;
@@ -1897,6 +1910,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
 #define PF_T16(DD) case DD: if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \
                             else hipLaunchKernelGGL((k_l2_tile16<false, DD>), grid16, dim3(256), 0, s, t, g32, n32); break;
                 PF_T16(16) PF_T16(32) PF_T16(48) PF_T16(64) PF_T16(80) PF_T16(96) PF_T16(112) PF_T16(128)
+                PF_T16(144) PF_T16(160) PF_T16(176) PF_T16(192) PF_T16(208) PF_T16(224) PF_T16(240) PF_T16(256)
 #undef PF_T16
                 default: break;                                       // (pf_flat_create keeps an image for these row lengths only)
             }

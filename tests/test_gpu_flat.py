@@ -399,7 +399,9 @@ def _search_both(pf, xb, xq, k):
 
 
 @pytest.mark.parametrize("d,nq,k", [(128, 300, 200), (64, 129, 10), (128, 1024, 100), (64, 65, 64),
-                                    (16, 200, 33), (32, 257, 100), (48, 130, 200), (80, 300, 50), (96, 513, 100), (112, 129, 17)])   # every multiple of 16 up to 128
+                                    (16, 200, 33), (32, 257, 100), (48, 130, 200), (80, 300, 50), (96, 513, 100), (112, 129, 17),   # every multiple of 16 up to 128
+                                    (144, 130, 100), (160, 300, 33), (176, 129, 200), (192, 257, 64), (208, 65, 10), (224, 200, 100), (240, 140, 17),
+                                    (256, 300, 200)])                                                                                # ... and up to 256: 128 x 64 tiles
 def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
     """exactly-representable data (integers, |v| <= 256): the bf16-operand tiles must return the fp32 loop's (D, I) and the
     oracle's, bit for bit -- including the extreme values +-256 and heavy ties"""
@@ -424,13 +426,14 @@ def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
         assert np.allclose(got16[0], Dr, rtol=RTOL, atol=0) and (np.sort(got16[1], axis=1) == np.sort(Ir, axis=1)).mean() > 0.99
 
 
-def test_exact16_dense_survivors_and_far_thresholds():
+@pytest.mark.parametrize("d", [128, 256])
+def test_exact16_dense_survivors_and_far_thresholds(d):
     """bf16 tiles under stress: base rows ordered by DEcreasing distance (every streamed row passes the filter: the verdict words are
     worked off in several rounds per flush, the candidate lists overflow into the exact rescan), and queries whose k-th distance lies
     far above their own norm (threshold term R below -2^22: the conservative-margin branch of the ninth k-step)"""
     import prefhetch_amd as pf
-    nb, nq, k, d = 40000, 130, 100, 128
-    m = (np.arange(nb)[::-1] * 129 // nb)                           # row i has m(i) entries of 2: its distance to a small query falls with i
+    nb, nq, k = 40000, 130, 100
+    m = (np.arange(nb)[::-1] * (d + 1) // nb)                       # row i has m(i) entries of 2: its distance to a small query falls with i
     xb = (np.arange(d)[None, :] < m[:, None]).astype(np.float32) * 2.0
     rng = np.random.default_rng(11)
     xq = rng.integers(0, 2, (nq, d)).astype(np.float32)
@@ -449,21 +452,23 @@ def test_exact16_dense_survivors_and_far_thresholds():
     assert (got16[1] == got32[1]).all() and (got16[0].view(np.uint32) == got32[0].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("d", [128, 256])
 @pytest.mark.parametrize("law", ["gaussian", "mixed_norms", "integers_with_one_fraction"])
-def test_bf16_filter_over_inexact_operands_is_bit_identical(law):
+def test_bf16_filter_over_inexact_operands_is_bit_identical(law, d):
     """operands that are NOT exactly representable: the bf16 tiles run as a conservative filter (thresholds lowered by the bound
     on the operands' rounding) and every survivor is re-evaluated by the fp32 chain -- (D, I) must equal the fp32-operand
     loop's bit for bit, whatever the norms look like"""
     import prefhetch_amd as pf
     rng = np.random.default_rng(17)
-    nb, nq, k, d = 60000, 200, 100, 128
+    nb, nq, k = 60000, 200, 100
     if law == "gaussian":
         xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
     elif law == "mixed_norms":                                       # rows of very different length: the margin is priced on the largest
         xb = rng.standard_normal((nb, d)) * rng.choice([0.01, 1.0, 30.0], (nb, 1))
         xq = rng.standard_normal((nq, d)) * rng.choice([0.1, 1.0, 10.0], (nq, 1))
     else:
-        xb, xq = rng.integers(0, 256, (nb, d)).astype(np.float64), rng.integers(0, 256, (nq, d)).astype(np.float64)
+        top = 256 if d <= 128 else 128                               # (|x|^2 + |y|^2 below 2^24)
+        xb, xq = rng.integers(0, top, (nb, d)).astype(np.float64), rng.integers(0, top, (nq, d)).astype(np.float64)
         xb[777, 5] = 0.5                                             # one inexact value: the whole base counts as inexact
     xb, xq = xb.astype(np.float32), xq.astype(np.float32)
     f = pf.FlatL2(xb, _dev())
@@ -483,14 +488,17 @@ def test_bf16_filter_over_inexact_operands_is_bit_identical(law):
 @pytest.mark.parametrize("nb,nq,k,d,law", [(100, 200, 50, 128, "int"), (8192, 130, 20, 128, "int"), (8193, 130, 20, 128, "int"), (20000, 65, 1024, 128, "int"),
                                             (50000, 300, 1024, 64, "int"), (30000, 129, 7, 64, "gauss"), (9000, 70, 200, 128, "gauss"),
                                             (70000, 257, 300, 128, "mixed"), (60000, 300, 100, 96, "gauss"), (60000, 200, 40, 48, "mixed"),
-                                            (40000, 129, 64, 16, "gauss"), (50000, 260, 200, 112, "int"), (50000, 140, 10, 80, "gauss")])
+                                            (40000, 129, 64, 16, "gauss"), (50000, 260, 200, 112, "int"), (50000, 140, 10, 80, "gauss"),
+                                            (50000, 260, 200, 256, "int"), (60000, 300, 100, 256, "gauss"), (40000, 130, 1024, 192, "mixed"), (100, 200, 50, 144, "int"),
+                                            (8193, 129, 20, 240, "gauss"), (70000, 140, 40, 160, "mixed")])
 def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
     """shapes around the seams of the batch path: a base smaller than one tile, exactly / one past the bootstrap chunk, the smallest
     batch, k = 1024 (merges of 2048 keys by one wave), d = 64, a single filtered tile -- bf16 tiles vs fp32 operands, bit for bit"""
     import prefhetch_amd as pf
     rng = np.random.default_rng(nb + nq)
     if law == "int":
-        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+        top = 256 if d <= 128 else 128                               # |x|^2 + |y|^2 below 2^24: the fp32 formula is exact and the oracle's distance is the same number
+        xb, xq = rng.integers(0, top, (nb, d)), rng.integers(0, top, (nq, d))
     elif law == "gauss":
         xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
     else:
@@ -508,13 +516,14 @@ def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
         assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
 
 
-def test_bf16_filter_worst_case_rounding():
+@pytest.mark.parametrize("d", [128, 256])
+def test_bf16_filter_worst_case_rounding(d):
     """the bound the filter margin is priced on, met with equality: every coordinate is +-(1 + 2^-8) c -- exactly halfway between two
     bf16 values, rounded DOWN by ties-to-even, so every product loses the full 2^-7 -- and queries are copies of base rows (x parallel
     to y, Cauchy-Schwarz tight, all rows of one norm): the true neighbours are where the bf16 dot product is furthest from the fp32 one"""
     import prefhetch_amd as pf
     rng = np.random.default_rng(23)
-    nb, nq, k, d = 30000, 160, 10, 128
+    nb, nq, k = 30000, 160, 10
     mag = np.float32(3.0) * np.float32(1.0 + 2.0 ** -8)
     xb = (rng.integers(0, 2, (nb, d)) * 2 - 1).astype(np.float32) * mag
     xq = (rng.integers(0, 2, (nq, d)) * 2 - 1).astype(np.float32) * mag
@@ -545,7 +554,7 @@ def test_exact16_path_refuses_inexact_data():
         f = pf.FlatL2(xb, dev)
         assert not f.exact16() and f.operands16() == 1                                                 # the image stays, as a filter's operand
     assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
-    for d in (100, 192, 256):                                                                          # row lengths the bf16 tiles are not built for
+    for d in (100, 264, 272, 320):                                                                     # row lengths the bf16 tiles are not built for
         assert pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).operands16() == 0
     assert pf.FlatL2(base, dev).operands16() == 2
 

@@ -13,23 +13,24 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for it in range(iters):
-    d = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128]))
+    d = int(rng.choice(np.arange(16, 257, 16)))
     nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 60000), rng.integers(60000, 400000)]))
     nq = int(rng.choice([rng.integers(1, 70), rng.integers(70, 300), rng.integers(300, 700)]))
     k = int(min(rng.choice([1, 7, 64, 200, 256, 257, 1024]), 1024))
     law = str(rng.choice(["int", "ties", "gauss", "mixed", "dups", "neg"]))
+    top = 256 if d <= 128 else 128       # (|x|^2 + |y|^2 < 2^24: the oracle's exact distance is what the fp32 formula returns)
     if law == "int":
-        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+        xb, xq = rng.integers(0, top, (nb, d)), rng.integers(0, top, (nq, d))
     elif law == "ties":
         xb, xq = rng.integers(0, 3, (nb, d)), rng.integers(0, 3, (nq, d))
     elif law == "neg":
-        xb, xq = rng.integers(-256, 257, (nb, d)), rng.integers(-256, 257, (nq, d))
+        xb, xq = rng.integers(-top, top + 1, (nb, d)), rng.integers(-top, top + 1, (nq, d))
     elif law == "gauss":
         xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
     elif law == "mixed":
         xb, xq = rng.standard_normal((nb, d)) * rng.choice([0.01, 1, 40], (nb, 1)), rng.standard_normal((nq, d)) * rng.choice([0.1, 1, 10], (nq, 1))
     else:
-        xb = rng.integers(0, 256, (max(nb // 50, 1), d))[rng.integers(0, max(nb // 50, 1), nb)]      # every row ~50 times
+        xb = rng.integers(0, top, (max(nb // 50, 1), d))[rng.integers(0, max(nb // 50, 1), nb)]      # every row ~50 times
         xq = xb[rng.integers(0, nb, nq)]
     xb, xq = np.ascontiguousarray(xb, np.float32), np.ascontiguousarray(xq, np.float32)
     f = pf.FlatL2(xb, dev)
