@@ -60,8 +60,12 @@ if what == "encround":           # the server side of the encrypted precise sear
     print("encround: %.3f ms per %d queries x %d candidates (%d products): %.0f encrypted precise queries/s" % (ms, B, K, B * fan, B / ms * 1e3))
     sys.exit(0)
 if what == "flat":
-    xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
-    xq = torch.randint(0, 256, (B, 128), generator=g, device=dev, dtype=torch.int32).float()
+    if os.environ.get("PF_RK_LAW") == "gauss":                      # N(0,1) rows: the bf16 tiles as a conservative filter
+        xb = torch.randn((1_000_000, 128), generator=g, device=dev)
+        xq = torch.randn((B, 128), generator=g, device=dev)
+    else:
+        xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
+        xq = torch.randint(0, 256, (B, 128), generator=g, device=dev, dtype=torch.int32).float()
     idx = pf.FlatL2(xb, dev)
     for _ in range(reps):
         idx.search(xq, 200)
