@@ -624,6 +624,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (define
 #ifndef PF_FLUSH_U
 #define PF_FLUSH_U 6
 #endif
+#ifndef PF_APPROX_UNROLL       // float4 pieces of a survivor's base row requested before the first is used (fp32 chain of the inexact path)
+#define PF_APPROX_UNROLL 8      // ... query rows staged in LDS (a walk's last flush)
+#endif
+#ifndef PF_APPROX_UNROLL2
+#define PF_APPROX_UNROLL2 4     // ... both rows from memory
+#endif
 #if PF_B16_TN == 64
 #define PF_FLUSH_INLINE __forceinline__
 #else
@@ -754,14 +760,14 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                     float acc = 0.f;
                     if (xstage) {
                         const float4 *x = reinterpret_cast<const float4 *>(xstage + (row - r0) * XP);
-#pragma unroll 8
+#pragma unroll PF_APPROX_UNROLL
                         for (int t = 0; t < D / 4; ++t) {
                             const float4 a = x[t], b = y[t];
                             acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
                         }
                     } else {
                         const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D);
-#pragma unroll 4
+#pragma unroll PF_APPROX_UNROLL2
                         for (int t = 0; t < D / 4; ++t) {
                             const float4 a = x[t], b = y[t];
                             acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);

@@ -14,8 +14,12 @@ from prefhetch_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
-xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
-xq = torch.randint(0, 256, (1024, 128), generator=g, device=dev, dtype=torch.int32).float()
+if os.environ.get("PF_RK_LAW") == "gauss":                          # N(0,1): the tiles as a conservative filter, survivors by the fp32 chain
+    xb = torch.randn((1_000_000, 128), generator=g, device=dev)
+    xq = torch.randn((1024, 128), generator=g, device=dev)
+else:
+    xb = torch.randint(0, 256, (1_000_000, 128), generator=g, device=dev, dtype=torch.int32).float()
+    xq = torch.randint(0, 256, (1024, 128), generator=g, device=dev, dtype=torch.int32).float()
 idx = pf.FlatL2(xb, dev)
 for _ in range(3):
     idx.search(xq, 200)
