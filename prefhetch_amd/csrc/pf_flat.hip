@@ -1116,7 +1116,12 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
-                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
+                #ifdef PF_ABL_EXACTFLUSH   // ablation (timing only, wrong results on inexact data): survivors by the 16-bit dot products whatever the operands
+                constexpr bool abl_exact = true;
+#else
+                constexpr bool abl_exact = false;
+#endif
+                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
