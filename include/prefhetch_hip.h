@@ -219,7 +219,7 @@ pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_h
 pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 
-/* 16-bit operands for the pre-filter (d = 64 or 128, any number of queries).  pf_flat_create keeps a bf16 image of the
+/* 16-bit operands for the pre-filter (d a multiple of 16 up to 256, any number of queries).  pf_flat_create keeps a bf16 image of the
  * base (nearest-even) and checks on the device, value by value, whether it IS the base: every value an integer of magnitude
  * <= 256 (SIFT, the reference's dataset -- 8-bit values, /root/reference/include/common/client_server_utils.h:10-20 --
  * qualifies); query tiles are checked the same way at every search.
