@@ -1706,7 +1706,10 @@ struct pf_flat {
 
 namespace {
 
-constexpr size_t BOOT_ROWS = 8192;         // bootstrap chunk (slab path)
+#ifndef PF_BOOT_ROWS
+#define PF_BOOT_ROWS 8192
+#endif
+constexpr size_t BOOT_ROWS = PF_BOOT_ROWS;  // bootstrap chunk (slab path); at most 8192 (radix_bootstrap keeps the chunk in registers)
 
 struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_qbad, total; };
 
