@@ -734,14 +734,18 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             // copied into LDS once, coalesced (row pitch D * 4 + 16 bytes: conflict-free 16-byte reads by 64 different rows).
             constexpr uint32_t XP = D * 4 + 16;
             // the tile buffers hold all 128 staged rows, or (64-column tiles) half of them: then the list is worked off in two halves by row
-            constexpr uint32_t XROWS = 2u * TN * (D + AUX16) * 2u >= 128u * XP ? 128u : 64u;
-            static_assert(2u * TN * (D + AUX16) * 2u >= XROWS * XP, "the staged query rows fit the two tile buffers");
+            // ... both of them at the walk's last flush, the one whose tile is done at a flush in mid-walk (the other holds the next tile): the list is
+            // worked off in rounds of as many query rows as fit -- 128 / 64 at d = 128, 64 / 32 at d = 256
+            constexpr uint32_t BUF = TN * (D + AUX16) * 2u;
+            constexpr uint32_t X_ALL = 2u * BUF >= 128u * XP ? 128u : 64u, X_ONE = BUF >= 128u * XP ? 128u : BUF >= 64u * XP ? 64u : 32u;
+            static_assert(2u * BUF >= X_ALL * XP && BUF >= X_ONE * XP, "the staged query rows fit the tile buffers");
+            const uint32_t XROWS = final ? X_ALL : X_ONE;
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
                 pd.rcnt[tid] = 0;
             }
-            for (uint32_t r0 = 0; r0 < (xstage ? 128u : XROWS); r0 += XROWS) {        // (without staging: one round over everything)
+            for (uint32_t r0 = 0; r0 < (xstage ? 128u : 1u); r0 += XROWS) {           // (without staging: one round over everything)
                 if (xstage) {
                     if (r0) __syncthreads();                              // the first half's readers are done
                     for (uint32_t i = tid; i < XROWS * (D / 4); i += 256) {
@@ -1115,13 +1119,14 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
                 uint32_t surv[MT][NJ];
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
-                // (the tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them)
+                // (both tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them; in mid-walk the
+                // buffer of the tile just finished is -- its readers passed the barrier above, the next request into it comes with the next tile)
                 #ifdef PF_ABL_EXACTFLUSH   // ablation (timing only, wrong results on inexact data): survivors by the 16-bit dot products whatever the operands
                 constexpr bool abl_exact = true;
 #else
                 constexpr bool abl_exact = false;
 #endif
-                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : nullptr, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : buf_cur, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
