@@ -60,9 +60,9 @@ def parse():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start the N rank processes as FRESH children of a process that has
-    not touched the GPU (no HIP call has happened yet: torch is imported, nothing else), one rank per GPU, rendezvous on
-    127.0.0.1.  Never an exec of this process."""
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as FRESH children of this one (which has launched
+    nothing: torch is imported and the devices are counted -- that count may initialise the HIP runtime here, which is why the ranks
+    are children and never an exec of this process), one rank per GPU, rendezvous on 127.0.0.1."""
     rehearsal = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1"
     have = torch.cuda.device_count()                     # the ranks are fresh CHILD processes either way (nothing is exec'd from here)
     if not rehearsal and have < args.gpus:
