@@ -875,6 +875,13 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #ifndef PF_DMA_SPREAD
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
+#ifdef PF_ABL_I8
+using i32x4v = __attribute__((ext_vector_type(4))) int;
+using i32x16v = __attribute__((ext_vector_type(16))) int;
+#define PF_MFMA16(A, B, C) __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, A), __builtin_bit_cast(i32x4v, B), __builtin_bit_cast(i32x16v, C), 0, 0, 0))
+#else
+#define PF_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
 template <bool FILTER, int D>                                       // D = row length (a multiple of 16 up to 256): every loop below is compile-time
 __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = typename Geo16Of<D>::type;
@@ -1053,6 +1060,10 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
             const int c = ks & 1, n = c ^ 1;
+#ifdef PF_ABL_I8   // ablation (timing only, wrong results): the matrix work, LDS reads and copies an 8-bit integer image would need -- every other
+            // k-step dropped, the kept ones issued as v_mfma_i32_32x32x32_i8 (same cycles as the bf16 instruction at twice the depth)
+            if (ks & 1) continue;
+#endif
             if (ks + 1 < D / 16) {
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH + (ks + 1) * 32);
@@ -1063,7 +1074,7 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             __builtin_amdgcn_sched_barrier(0);
 #if PF_DMA_SPREAD && !defined(PF_ABL_NODMA)
             // sweeps ks and (for the last step, when D / 16 < SWEEPS + 1) the rest, behind the step's first matrix instruction
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[0][ks], b[c][0], acc[0][0], 0, 0, 0);
+            acc[0][0] = PF_MFMA16(afrag[0][ks], b[c][0], acc[0][0]);
             if (more) {
                 constexpr uint32_t STEPS = D / 16;
                 if ((uint32_t)ks + 1 < STEPS) stage_sweep(ct + 1, buf_nxt, ks);
@@ -1076,7 +1087,7 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
-                    if (i || jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
+                    if (i || jj) acc[i][jj] = PF_MFMA16(afrag[i][ks], b[c][jj], acc[i][jj]);
 #else
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -1085,6 +1096,7 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef PF_ABL_I8   // (an integer image folds the thresholds into the accumulators' initial values)
         if constexpr (FILTER) {
             constexpr int c = (D / 16) & 1;
 #pragma unroll
@@ -1092,6 +1104,7 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux[i], b[c][jj], acc[i][jj], 0, 0, 0);
         }
+#endif
         PF_FSTAMP(3);
         if constexpr (FILTER) {
             uint32_t s1[NJ];
