@@ -233,6 +233,14 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *p
  * *active_out (may be NULL): 2 = on with an exactly representable base, 1 = on as a filter over an inexact base, 0 = off. */
 pf_status pf_flat_exact16(pf_flat *idx, int mode, int *active_out);
 
+/* 8-bit integer operands for the pre-filter.  When EVERY value of the base is an integer in [0, 255] (SIFT: the reference's
+ * dataset, /root/reference/include/common/client_server_utils.h:10-20) and d is a multiple of 32 up to 128, pf_flat_create also
+ * keeps an int8 image (value - 128) and the filtered tiles of a query tile that is 8-bit as well (checked on the device at every
+ * search) run v_mfma_i32_32x32x32_i8: exact integer accumulators, twice the depth per instruction of the bf16 form, half the
+ * bytes through LDS.  Survivors are evaluated exactly as on the bf16 path: (D, I) are bit-identical to the fp32-operand loop's.
+ * mode 1 on (default), 0 off (the bf16 tiles then run on the same data), -1 query; active_out: 1 when an image exists and is on. */
+pf_status pf_flat_operands8(pf_flat *idx, int mode, int *active_out);
+
 /* pf_flat_search that also (or only: D and I may then be NULL) writes the exchange record of the multi-GPU gather,
  * packed[q][i] = { uint32 id low word, uint32 id high word, uint32 distance bits }, 12 bytes per result, straight from
  * the selection kernel -- the block a rank contributes to the ONE all-gather of SURVEY.md section 8(e) needs no packing

@@ -17,7 +17,7 @@ SYMBOLS = [
     "pf_ntt_forward", "pf_ntt_inverse", "pf_ntt_forward_to", "pf_ntt_inverse_to", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
     "pf_ct_pt_mul", "pf_ct_pt_mul_fanout", "pf_apply_galois", "pf_apply_galois_ct", "pf_poly_mul_monomial", "pf_poly_addsub_monomial", "pf_key_switch", "pf_key_switch_reserve", "pf_pack_rows", "pf_pack_rows_ntt", "pf_ct_rows_mul", "pf_ct_pt_dot",
     "pf_flat_create", "pf_flat_destroy", "pf_flat_info", "pf_flat_search", "pf_l2_gathered", "pf_gather_rows",
-    "pf_flat_reserve", "pf_flat_search_packed", "pf_flat_exact16",
+    "pf_flat_reserve", "pf_flat_search_packed", "pf_flat_exact16", "pf_flat_operands8",
     "pf_multi_create", "pf_multi_destroy", "pf_multi_info", "pf_multi_ring", "pf_multi_flat", "pf_multi_reserve", "pf_multi_member",
     "pf_multi_flat_search", "pf_multi_ct_pt_mul", "pf_multi_synchronize", "pf_multi_flat_search_host",
     "pf_ivfpq_create", "pf_ivfpq_destroy", "pf_ivfpq_add_encoded", "pf_ivfpq_info", "pf_ivfpq_get_list", "pf_ivfpq_search_lists",
@@ -79,6 +79,7 @@ def _load():
     lib.pf_gather_rows.argtypes = [vp, vp, sz, vp, vp]
     lib.pf_flat_reserve.argtypes = [vp, sz, u32]
     lib.pf_flat_exact16.argtypes = [vp, i32, C.POINTER(C.c_int)]
+    lib.pf_flat_operands8.argtypes = [vp, i32, C.POINTER(C.c_int)]
     lib.pf_flat_search_packed.argtypes = [vp, vp, sz, u32, vp, vp, vp, vp]
     lib.pf_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), i32, i32]
     lib.pf_multi_destroy.argtypes = [vp]

@@ -289,6 +289,13 @@ class FlatL2:
         check(lib.pf_flat_exact16(self._h, int(mode), C.byref(a)), "pf_flat_exact16")
         return int(a.value)
 
+    def operands8(self, mode=-1):
+        """int8 tiles of the batch pre-filter (pf_flat_operands8): mode 1 on (default), 0 off, -1 query.  True when the base is 8-bit data
+        (every value an integer in [0, 255], d a multiple of 32 up to 128), its int8 image exists and the path is on."""
+        a = C.c_int()
+        check(lib.pf_flat_operands8(self._h, int(mode), C.byref(a)), "pf_flat_operands8")
+        return bool(a.value)
+
     def exact16(self, mode=-1):
         """True when the bf16 tiles are on AND the base passed the on-device exactness check (operands16() == 2)."""
         return self.operands16(mode) == 2

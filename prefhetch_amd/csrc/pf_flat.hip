@@ -107,22 +107,29 @@ constexpr uint32_t PREP_MAX_D = 256;                            // rows up to 12
 template <uint32_t ROWS, uint32_t MAXD>
 __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
                                                   uint16_t *__restrict__ x16, uint32_t pitch16, bool aux, uint32_t *__restrict__ inexact,
-                                                  uint32_t rows_per_flag) {
+                                                  uint32_t rows_per_flag, int8_t *__restrict__ x8 = nullptr, uint32_t pitch8 = 0) {
     __shared__ float tile[ROWS * (MAXD + 1)];
     const size_t r0 = (size_t)blockIdx.x * ROWS;
     const uint32_t rows = (uint32_t)(n - r0 < ROWS ? n - r0 : ROWS), total = rows * d, lane = threadIdx.x;
     const float *src = x + r0 * d;
-    uint32_t bad = 0;                                             // bit (row / rows_per_flag within this block's span) ... kept per lane
+    uint32_t bad = 0, bad8 = 0;                                   // bit (row / rows_per_flag within this block's span) ... kept per lane
     for (uint32_t e = lane; e < total; e += 64) {
         const float v = src[e];
         const uint32_t r = e / d, k = e - r * d;
         tile[r * (d + 1) + k] = v;
         if (x16) x16[(r0 + r) * pitch16 + k] = bf16_rne(v);                              // exact when the value passes; nearest otherwise
-        if (inexact && !bf16_exact(v)) bad |= 1u << (rows_per_flag ? ((r0 + r) / rows_per_flag - r0 / rows_per_flag) : 0);
+        const uint32_t fbit = 1u << (rows_per_flag ? ((r0 + r) / rows_per_flag - r0 / rows_per_flag) : 0);
+        if (inexact && !bf16_exact(v)) bad |= fbit;
+        if (x8) {                                                                        // 8-bit data: value - 128 as int8 (meaningless, and flagged, otherwise)
+            const bool ok8 = v == rintf(v) && v >= 0.f && v <= 255.f;
+            x8[(r0 + r) * (size_t)pitch8 + k] = (int8_t)(ok8 ? (int)v - 128 : 0);
+            if (!ok8) bad8 |= fbit;
+        }
     }
-    if (bad) {                                                    // a block of <= 64 rows touches at most two flags (rows_per_flag >= 64) or one
-        if (bad & 1u) atomicOr(&inexact[rows_per_flag ? r0 / rows_per_flag : 0], 1u);
-        if (bad & 2u) atomicOr(&inexact[r0 / rows_per_flag + 1], 1u);
+    if (bad | bad8) {                                             // a block of <= 64 rows touches at most two flags (rows_per_flag >= 64) or one
+        const uint32_t w0 = (bad & 1u) | ((bad8 & 1u) << 2), w1 = ((bad >> 1) & 1u) | (((bad8 >> 1) & 1u) << 2);
+        if (w0) atomicOr(&inexact[rows_per_flag ? r0 / rows_per_flag : 0], w0);
+        if (w1) atomicOr(&inexact[r0 / rows_per_flag + 1], w1);
     }
     __syncthreads();
     if (lane < rows) {
@@ -139,6 +146,14 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             w[2] = BF16_ONE | (BF16_ONE << 16);
             w[3] = 0;
             *reinterpret_cast<u32x4 *>(x16 + (r0 + lane) * pitch16 + d) = w;        // 16-byte aligned: d and pitch16 are multiples of 8
+        }
+        if (x8 && aux) {                                         // the column's half of the integer threshold (tile16_walk): c0 = -floor(C / 2), C = |y|^2 - 256 sum (y - 128)
+            int sy = 0;
+            for (uint32_t k = 0; k < d; ++k) sy += (int)row[k] - 128;
+            const int Cc = (int)acc - 256 * sy;
+            u32x4 w;
+            w[0] = (uint32_t)(-(Cc >> 1)); w[1] = 0; w[2] = 0; w[3] = 0;
+            *reinterpret_cast<u32x4 *>(x8 + (r0 + lane) * (size_t)pitch8 + d) = w;   // 16-byte aligned: d and pitch8 are multiples of 16
         }
     }
 }
@@ -177,6 +192,9 @@ struct TileArgs {
     // exactly-representable data (see "bf16 operands" below): 16-bit images of the queries / the base, and per 128-query
     // tile a word that is non-zero when some value of the tile is NOT exactly representable (then the fp32 loop runs)
     const uint16_t *xq16; const uint16_t *xb16; const uint32_t *q_inexact;
+    // 8-bit data (every value an integer in [0, 255]: "8-bit integer operands" below): images of value - 128 as int8, the base rows with
+    // their half of the threshold behind them; q_inexact bit 2 = some value of the query tile is outside that range
+    const int8_t *xq8; const int8_t *xb8;
     uint32_t base_exact;    // every value of the base is exactly representable in bf16
     float bn_max;           // largest |y|^2 of the base (the inexact path's filter margin)
 };
@@ -875,27 +893,30 @@ __device__ __forceinline__ void l2_tile_verdicts16(f32x16 (&acc)[GEO::MI][GEO::N
 #ifndef PF_DMA_SPREAD
 #define PF_DMA_SPREAD 1       // the LDS-DMA requests of the next column tile interleaved with this tile's matrix instructions (k_l2_tile16)
 #endif
-#ifdef PF_ABL_I8
 using i32x4v = __attribute__((ext_vector_type(4))) int;
 using i32x16v = __attribute__((ext_vector_type(16))) int;
-#define PF_MFMA16(A, B, C) __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, A), __builtin_bit_cast(i32x4v, B), __builtin_bit_cast(i32x16v, C), 0, 0, 0))
-#else
-#define PF_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
-#endif
-template <bool FILTER, int D>                                       // D = row length (a multiple of 16 up to 256): every loop below is compile-time
-__global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
+// one matrix instruction of the tile loop on 16-byte operand fragments: 32 x 32 x 16 bf16 -> fp32, or 32 x 32 x 32 int8 -> int32 (the accumulator
+// registers hold the integers' bit patterns; the verdict sweep only reads their sign bits)
+template <bool I8>
+__device__ __forceinline__ f32x16 tile_mma(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (I8)
+        return __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a), __builtin_bit_cast(i32x4v, b), __builtin_bit_cast(i32x16v, c), 0, 0, 0));
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// I8: the operands are the int8 images (8-bit data), the matrix instruction v_mfma_i32_32x32x32_i8 -- the cycles of the bf16 instruction at twice
+// the depth, 16 instead of 36 of them per tile at d = 128, half the bytes copied into and read from LDS.  The accumulators start at the
+// (row + column) halves of the threshold instead of zero (what the ninth k-step does for bf16) and are exact integers.
+constexpr int AUX8 = 16;                        // bytes a base row of the int8 image carries behind its d values: c0 (int32), 12 spare
+template <bool FILTER, int D, bool I8>                              // D = row length (a multiple of 16 up to 256): every loop below is compile-time
+__device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t group, const uint32_t n_groups, char *smem, float *stage, Pend16 &pend,
+                                            const uint32_t qt, const uint32_t grp, const uint32_t qflags) {
     using GEO = typename Geo16Of<D>::type;
-    constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = (D + (int)AUX16) * 2;
+    constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = I8 ? D + AUX8 : (D + (int)AUX16) * 2;
+    constexpr int KS = I8 ? 32 : 16, STEPS = D / KS;                 // depth of a matrix instruction, k-steps of a tile
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
-    constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
-    static_assert(PITCH % 32 == 16 && (TN == 128 || TN == 64) && TM == 128, "odd row pitch in 16-byte units; 128 x 128 or 128 x 64 tiles");
-    __shared__ __align__(16) char smem[SMEM];
-    __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
-    __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
+    static_assert(PITCH % 32 == 16 && (TN == 128 || TN == 64) && TM == 128 && D % KS == 0 && (!I8 || FILTER), "odd row pitch in 16-byte units; 128 x 128 or 128 x 64 tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const uint32_t qt = j % p.n_qtiles, grp = (j / p.n_qtiles) * 8 + xcd;
-    if (grp >= n_groups) return;
     if constexpr (FILTER) {
         if (tid < TM) pend.rcnt[tid] = 0;
         if (tid == 0) pend.n = 0;
@@ -909,9 +930,8 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     // A query tile whose candidate lists overflowed in an earlier chunk (bit 1, set by the selection kernel) is one the bf16
     // tiles do not filter -- every distance within the rounding of the operands of the threshold: margin ~ 2^-8 (|x|^2 + |y|^2)
     // against a spread of distances far below that -- and runs fp32 tiles from then on.
-    const uint32_t qflags = p.q_inexact[qt];                        // workgroup-uniform
-    const bool approx = !p.base_exact || (qflags & 1u);
-    if ((!FILTER && approx) || (FILTER && (qflags & 2u))) {
+    const bool approx = !I8 && (!p.base_exact || (qflags & 1u));    // (qflags: workgroup-uniform; the caller picked I8 for exact 8-bit operands only)
+    if (!I8 && ((!FILTER && approx) || (FILTER && (qflags & 2u)))) {
         for (uint32_t ct = ct0; ct < ct1; ++ct) {
             l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
             __syncthreads();
@@ -930,7 +950,8 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     float bn_next[NJ];
     // sweep `it` (0 .. SWEEPS: the last one is the remainder) of column tile ct into buf
     auto stage_sweep = [&](uint32_t ct, char *buf, uint32_t it) {
-        const char *src = reinterpret_cast<const char *>(p.xb16 + (p.nb_first + (size_t)ct * TN) * (size_t)(D + AUX16)) + tid * 16;
+        const char *img = I8 ? reinterpret_cast<const char *>(p.xb8) : reinterpret_cast<const char *>(p.xb16);
+        const char *src = img + (p.nb_first + (size_t)ct * TN) * (size_t)PITCH + tid * 16;
         char *dst = buf + wave * 1024;
         if (it < SWEEPS)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4096 * it),
@@ -958,15 +979,17 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     // The query operand never changes during the walk: each wave keeps its fragments in registers (lane l: row l & 31 of each
     // 32-row block, 8 consecutive k of every 16-deep step = 16 bytes of the bf16 row image; rows past the end re-read the last
     // valid row -- their products land in accumulator rows the epilogue never emits)
-    bf16x8 afrag[MI][D / 16];
+    // (int8: lane l holds 16 consecutive k of every 32-deep step, again 16 bytes)
+    bf16x8 afrag[MI][STEPS];
     {
-        const uint16_t *abase = p.xq16 + q0 * (size_t)D;
+        const char *abase = I8 ? reinterpret_cast<const char *>(p.xq8 + q0 * (size_t)D) : reinterpret_cast<const char *>(p.xq16 + q0 * (size_t)D);
+        constexpr int ESZ = I8 ? 1 : 2;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const uint32_t r = wm + 32 * i + (lane & 31);
-            const uint16_t *row = abase + (r < q_valid ? r : q_valid - 1) * D + (lane >> 5) * 8;
+            const char *row = abase + ((size_t)(r < q_valid ? r : q_valid - 1) * D + (lane >> 5) * (KS / 2)) * ESZ;
 #pragma unroll
-            for (int ks = 0; ks < D / 16; ++ks) afrag[i][ks] = *reinterpret_cast<const bf16x8 *>(row + ks * 16);
+            for (int ks = 0; ks < STEPS; ++ks) afrag[i][ks] = *reinterpret_cast<const bf16x8 *>(row + ks * 32);
         }
     }
     float row_qn = 0.f, row_tau = -INFINITY;                        // rows past nq: nothing passes
@@ -974,13 +997,42 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
         if (tid < TM && q0 + tid < p.nq) { row_qn = p.qn[q0 + tid]; row_tau = p.tau[q0 + tid]; }
         // the rows of the query tile are the same for every column tile: staged once
         l2_tile_stage_rows<GEO, true>(stage, tid, row_qn, row_tau);
+        if constexpr (I8) {
+            // Integer thresholds.  With x' = x - 128, y' = y - 128 and S = sum x'y' (what the matrix instruction accumulates):
+            // x.y = S + 128 (sum x' + sum y') + 16384 d, and dist < tau <=> 2 S > R + C with the row's R = |x|^2 - tau - 256 sum x' - 32768 d
+            // and the column's C = |y|^2 - 256 sum y' (all exact integers below 2^26).  2 S > T <=> S >= floor(T / 2) + 1; the accumulators
+            // start at r0 + c0 = -(floor(R / 2) + 1) - floor(C / 2) >= -(floor((R + C) / 2) + 1): a distance can pass only where S + r0 + c0 >= 0
+            // (a superset by at most the one value at the boundary -- every survivor's distance is evaluated exactly by the flush).
+            if (tid < TM) {
+                int r0 = -(1 << 30);                                 // rows past nq: nothing passes
+                if (q0 + tid < p.nq) {
+                    if (row_tau == INFINITY) r0 = 1 << 30;           // fewer than k results so far: everything passes
+                    else {
+                        const uint32_t *w = reinterpret_cast<const uint32_t *>(p.xq8 + (q0 + tid) * (size_t)D);
+                        int sx = 0;
+#pragma unroll 8
+                        for (int t = 0; t < D / 4; ++t) sx = __builtin_amdgcn_sdot4((int)w[t], 0x01010101, sx, false);
+                        const int R = (int)row_qn - (int)row_tau - 256 * sx - 32768 * D;
+                        r0 = -(R >> 1) - 1;                          // (>> of a negative int: floor)
+                    }
+                }
+                reinterpret_cast<int *>(stage)[3 * TM + tid] = r0;
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the row half of the threshold k-step: lanes 0..31 carry (1, 1, 1, -r0, -r1, -r2, 0, 0) of their row for k = 0..7, lanes
     // 32..63 (k = 8..15) zeros; r0 + r1 + r2 = R (header comment)
     bf16x8 a_aux[MI];
-    if constexpr (FILTER) {
+    int r0v[I8 ? MI : 1][16];                                         // int8: the row halves of the thresholds of this lane's accumulator rows
+    if constexpr (I8) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r0v[i][r] = reinterpret_cast<const int *>(stage)[3 * TM + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    }
+    if constexpr (FILTER && !I8) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int arow = wm + 32 * i + (lane & 31);
@@ -1043,41 +1095,47 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             bnv[jj] = FILTER ? 0.f : bn_next[jj];
         }
         if constexpr (!FILTER) { if (ct + 1 < ct1) fetch_bn(ct + 1); }
-        f32x16 acc[MI][NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
         // column fragments of k-step s+1 are read from LDS while the matrix instructions of step s run (fenced: left to
         // itself hipcc hoists every fragment read of the tile to the top)
         const char *fbx = buf_cur + (wn + (lane & 31)) * PITCH, *fb = fbx + (lane >> 5) * 16;
+        f32x16 acc[MI][NJ];
+        if constexpr (I8) {                                          // the thresholds' halves instead of zero: row half from registers, column half behind the row
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int c0v = *reinterpret_cast<const int *>(fbx + 32 * jj * PITCH + D);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jj][r] = __builtin_bit_cast(float, r0v[i][r] + c0v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+        }
         bf16x8 b[2][NJ];
         PF_FSTAMP(2);
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) b[0][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH);
 #pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
+        for (int ks = 0; ks < STEPS; ++ks) {
             const int c = ks & 1, n = c ^ 1;
-#ifdef PF_ABL_I8   // ablation (timing only, wrong results): the matrix work, LDS reads and copies an 8-bit integer image would need -- every other
-            // k-step dropped, the kept ones issued as v_mfma_i32_32x32x32_i8 (same cycles as the bf16 instruction at twice the depth)
-            if (ks & 1) continue;
-#endif
-            if (ks + 1 < D / 16) {
+            if (ks + 1 < STEPS) {
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fb + 32 * jj * PITCH + (ks + 1) * 32);
-            } else if constexpr (FILTER) {                           // the threshold words behind the row: same 16 bytes for both lane halves
+            } else if constexpr (FILTER && !I8) {                    // the threshold words behind the row: same 16 bytes for both lane halves
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) b[n][jj] = *reinterpret_cast<const bf16x8 *>(fbx + 32 * jj * PITCH + D * 2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #if PF_DMA_SPREAD && !defined(PF_ABL_NODMA)
-            // sweeps ks and (for the last step, when D / 16 < SWEEPS + 1) the rest, behind the step's first matrix instruction
-            acc[0][0] = PF_MFMA16(afrag[0][ks], b[c][0], acc[0][0]);
+            // sweeps ks and (for the last step, when STEPS < SWEEPS + 1) the rest, behind the step's first matrix instruction
+            acc[0][0] = tile_mma<I8>(afrag[0][ks], b[c][0], acc[0][0]);
             if (more) {
-                constexpr uint32_t STEPS = D / 16;
-                if ((uint32_t)ks + 1 < STEPS) stage_sweep(ct + 1, buf_nxt, ks);
+                if (ks + 1 < STEPS) stage_sweep(ct + 1, buf_nxt, ks);
                 else {
 #pragma unroll
                     for (uint32_t it = STEPS - 1; it <= SWEEPS; ++it) stage_sweep(ct + 1, buf_nxt, it);
@@ -1087,24 +1145,22 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
-                    if (i || jj) acc[i][jj] = PF_MFMA16(afrag[i][ks], b[c][jj], acc[i][jj]);
+                    if (i || jj) acc[i][jj] = tile_mma<I8>(afrag[i][ks], b[c][jj], acc[i][jj]);
 #else
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[i][ks], b[c][jj], acc[i][jj], 0, 0, 0);
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = tile_mma<I8>(afrag[i][ks], b[c][jj], acc[i][jj]);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef PF_ABL_I8   // (an integer image folds the thresholds into the accumulators' initial values)
-        if constexpr (FILTER) {
-            constexpr int c = (D / 16) & 1;
+        if constexpr (FILTER && !I8) {
+            constexpr int c = STEPS & 1;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux[i], b[c][jj], acc[i][jj], 0, 0, 0);
         }
-#endif
         PF_FSTAMP(3);
         if constexpr (FILTER) {
             uint32_t s1[NJ];
@@ -1145,6 +1201,26 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             }
         }
     }
+}
+
+template <bool FILTER, int D>
+__global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
+    using GEO = typename Geo16Of<D>::type;
+    constexpr int TM = GEO::TM, TN = GEO::TN, PITCH = (D + (int)AUX16) * 2;
+    constexpr size_t SMEM = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
+    __shared__ __align__(16) char smem[SMEM];
+    __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
+    __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint32_t qt = j % p.n_qtiles, grp = (j / p.n_qtiles) * 8 + xcd;
+    if (grp >= n_groups) return;
+    const uint32_t qflags = p.q_inexact[qt];                        // workgroup-uniform
+    // 8-bit data on both sides (the base's image exists only then; bit 2 of the tile's word: a query value outside [0, 255]; bit 1: its
+    // lists overflowed, fp32 tiles from then on): the int8 matrix instruction.  Anything else: bf16 operands.
+    if constexpr (FILTER && D % 32 == 0 && D <= 128) {
+        if (p.xb8 && !(qflags & 7u)) { tile16_walk<true, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags); return; }
+    }
+    tile16_walk<FILTER, D, false>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
 }
 
 // ---- selection -----------------------------------------------------------------------------------
@@ -1711,6 +1787,8 @@ struct pf_flat {
     bool exact16 = false;         // EVERY value of the base passed the on-device exactness check: the image is the matrix itself
     float bn_max = 0.f;           // largest row norm (the margin of the bf16 tiles as a filter over inexact operands)
     bool use16 = true;            // pf_flat_exact16: the caller may switch the 16-bit operand path off
+    int8_t *xb8 = nullptr;        // 8-bit data only (every value an integer in [0, 255]; d a multiple of 32 up to 128): rows of d values - 128 + AUX8 threshold bytes
+    bool use8 = true;             // pf_flat_operands8: the caller may switch the int8 tiles off (the bf16 tiles then run on the same data)
     // workspace (grown outside graph capture)
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -1729,7 +1807,7 @@ namespace {
 #endif
 constexpr size_t BOOT_ROWS = PF_BOOT_ROWS;  // bootstrap chunk (slab path); at most 8192 (radix_bootstrap keeps the chunk in registers)
 
-struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_qbad, total; };
+struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_q8, off_qbad, total; };
 
 WsPlan plan_ws(size_t nb, size_t nq, uint32_t k, uint32_t d) {
     WsPlan w{};
@@ -1747,6 +1825,7 @@ WsPlan plan_ws(size_t nb, size_t nq, uint32_t k, uint32_t d) {
     w.off_cand = o; o += up(nq * w.cap * 8);
     w.off_slab = o; o += up(nq * w.slab_ld * 4);
     w.off_q16 = o; o += up(nq * (size_t)d * 2);
+    w.off_q8 = o; o += up(nq * (size_t)d);
     w.off_qbad = o; o += up(((nq + 127) / 128) * 4);
     w.total = o;
     return w;
@@ -1780,6 +1859,7 @@ pf_status pf_flat_destroy(pf_flat *f) {
         DeviceGuard g(f->device);
         if (f->xb) (void)hipFree(f->xb);
         if (f->xb16) (void)hipFree(f->xb16);
+        if (f->xb8) (void)hipFree(f->xb8);
         if (f->bn) (void)hipFree(f->bn);
         if (f->ws) (void)hipFree(f->ws);
     }
@@ -1817,7 +1897,16 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             if (f->xb16) { (void)hipFree(f->xb16); f->xb16 = nullptr; }
             if (flag) { (void)hipFree(flag); flag = nullptr; }
         }
-        if (d <= 128) hipLaunchKernelGGL((k_rows_prep<64, 128>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
+        // 8-bit data (SIFT, the reference's dataset): an int8 image for the integer matrix instruction where the rows are whole 32-deep k-steps
+        // (same zero-row padding; rows of d values - 128 + AUX8 bytes).  Kept only if EVERY value is an integer in [0, 255] (flag bit 2).
+        const size_t bytes8 = (nb + 128) * (size_t)(d + AUX8);
+        if (f->xb16 && d % 32 == 0 && d <= 128 && getenv("PF_FLAT_NO_I8") == nullptr &&
+            (hipMalloc((void **)&f->xb8, bytes8) != hipSuccess || hipMemset(f->xb8, 0, bytes8) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (f->xb8) { (void)hipFree(f->xb8); f->xb8 = nullptr; }
+        }
+        if (d <= 128) hipLaunchKernelGGL((k_rows_prep<64, 128>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u,
+                                         f->xb8, d + (uint32_t)AUX8);
         else if (d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<32, PREP_MAX_D>), dim3((unsigned)((nb + 31) / 32)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
         else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
         e = hipGetLastError();
@@ -1826,7 +1915,8 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             uint32_t inexact = 1;
             if (e == hipSuccess) e = hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost);
             (void)hipFree(flag);
-            f->exact16 = f->xb16 && !inexact;       // inexact values: the image stays, as the operand of a conservative filter
+            f->exact16 = f->xb16 && !(inexact & 1u);       // inexact values: the image stays, as the operand of a conservative filter
+            if (f->xb8 && (inexact & 5u)) { (void)hipFree(f->xb8); f->xb8 = nullptr; }     // some value is not an integer in [0, 255]
             if (e == hipSuccess && f->xb16 && !f->exact16) {
                 hipLaunchKernelGGL(k_aux_margin, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb16, f->bn, nb, d, d + AUX16);
                 e = hipGetLastError();
@@ -1838,7 +1928,7 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             e = hipMemcpy(norms.data(), f->bn, nb * 4, hipMemcpyDeviceToHost);
             bool finite = true;
             for (float v : norms) { finite = finite && std::isfinite(v); if (v > f->bn_max) f->bn_max = v; }
-            if (!finite) { (void)hipFree(f->xb16); f->xb16 = nullptr; f->exact16 = false; }
+            if (!finite) { (void)hipFree(f->xb16); f->xb16 = nullptr; f->exact16 = false; if (f->xb8) { (void)hipFree(f->xb8); f->xb8 = nullptr; } }
         }
     }
     if (e != hipSuccess) { pf_flat_destroy(f); return fail(e == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, std::string("pf_flat_create: ") + hipGetErrorString(e)); }
@@ -1859,6 +1949,13 @@ pf_status pf_flat_exact16(pf_flat *f, int mode, int *active) {
     if (!f || mode < -1 || mode > 1) return fail(PF_ERR_INVALID_ARG, "pf_flat_exact16: index, and mode -1 (query), 0 (off) or 1 (on where exact)");
     if (mode >= 0) f->use16 = mode == 1;
     if (active) *active = f->xb16 && f->use16 ? (f->exact16 ? 2 : 1) : 0;
+    return PF_OK;
+}
+
+pf_status pf_flat_operands8(pf_flat *f, int mode, int *active) {
+    if (!f || mode < -1 || mode > 1) return fail(PF_ERR_INVALID_ARG, "pf_flat_operands8: index, and mode -1 (query), 0 (off) or 1 (on where the data is 8-bit)");
+    if (mode >= 0) f->use8 = mode == 1;
+    if (active) *active = f->xb8 && f->use8 && f->xb16 && f->use16 ? 1 : 0;
     return PF_OK;
 }
 
@@ -1905,11 +2002,14 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
     if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
+    const bool b8 = b16 && f->xb8 && f->use8;                       // int8 tiles for the query tiles that turn out to be 8-bit too (flag bit 2, set by the kernel below)
+    int8_t *q8 = reinterpret_cast<int8_t *>(base + w.off_q8);
     if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, f->d,
-                                               false, b16 ? qbad : nullptr, 128u);
+                                               false, b16 ? qbad : nullptr, 128u, b8 ? q8 : nullptr, f->d);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
     t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = f->exact16 ? 1u : 0u; t.bn_max = f->bn_max;
+    t.xq8 = b8 ? q8 : nullptr; t.xb8 = b8 ? f->xb8 : nullptr;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};
