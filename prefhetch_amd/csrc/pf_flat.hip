@@ -653,14 +653,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (define
 #else
 #define PF_FLUSH_INLINE __forceinline__
 #endif
-template <int D, int MT, int NJ, int TN>
+template <int D, int MT, int NJ, int TN, bool I8 = false>
 __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     // lanes per survivor: LU = D / 8 of them hold 16 bytes of both rows each, rounded up to a power of two (L) for the DPP sum
-    constexpr uint32_t LU = D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : LU <= 16 ? 16 : 32, G = 256 / L;         // G survivors per pass
+    // (I8: the rows of the int8 images, 16 values per lane: half the lanes and half the bytes per survivor, twice the survivors per pass)
+    constexpr uint32_t LU = I8 ? D / 16 : D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : LU <= 16 ? 16 : 32, G = 256 / L;         // G survivors per pass
     const int lane = tid & 63;
     uint32_t left = 0;
 #pragma unroll
@@ -818,10 +819,16 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 const uint32_t e = e0 + u * G + g < n ? e0 + u * G + g : n - 1;     // idle groups of the last pass repeat the last survivor
                 loc[u] = pd.loc[e]; id[u] = pd.id[e];
                 if (LU == L || l < LU) {
-                    va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + loc[u]) * (size_t)D + 8 * l);
-                    vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
+                    if constexpr (I8) {
+                        va[u] = *reinterpret_cast<const u32x4 *>(p.xq8 + (q0 + loc[u]) * (size_t)D + 16 * l);
+                        vb[u] = *reinterpret_cast<const u32x4 *>(p.xb8 + (size_t)id[u] * (D + 16) + 16 * l);
+                    } else {
+                        va[u] = *reinterpret_cast<const u32x4 *>(p.xq16 + (q0 + loc[u]) * (size_t)D + 8 * l);
+                        vb[u] = *reinterpret_cast<const u32x4 *>(p.xb16 + (size_t)id[u] * (D + AUX16) + 8 * l);
+                    }
                 } else {
-                    va[u] = u32x4{0, 0, 0, 0}; vb[u] = u32x4{0, 0, 0, 0};          // lanes past the row (D / 8 not a power of two)
+                    constexpr uint32_t Z = I8 ? 0x80808080u : 0u;                  // (int8 image: value 0 is stored as -128)
+                    va[u] = u32x4{Z, Z, Z, Z}; vb[u] = u32x4{Z, Z, Z, Z};          // lanes past the row (its lanes are not a power of two)
                 }
                 bnv[u] = p.bn[id[u]];
             }
@@ -842,6 +849,20 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float s = 0.f;
+                if constexpr (I8) {
+                    // the stored bytes are value - 128: flipping the top bit gives the value back as an unsigned byte, and v_dot4_u32_u8 the exact x.y
+                    uint32_t si = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t wa = va[u][w] ^ 0x80808080u, wb = vb[u][w] ^ 0x80808080u;
+                        si = __builtin_amdgcn_udot4(wa, wb, si, false);
+                    }
+                    si += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)si, 0xB1, 0xf, 0xf, true);                            // quad_perm [1,0,3,2]
+                    if constexpr (L >= 4) si += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)si, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+                    if constexpr (L >= 8) si += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)si, 0x141, 0xf, 0xf, true);     // row_half_mirror
+                    static_assert(!I8 || L <= 8, "int8 rows of at most 128 values");
+                    s = (float)si;                                     // below 2^24: exact
+                } else {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint32_t wa = va[u][w], wb = vb[u][w];     // through scalars: __builtin_bit_cast applied to va[u][w] itself reads element 0 four times (hipcc 7.2)
@@ -853,6 +874,7 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 if constexpr (L >= 8) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));    // row_half_mirror
                 if constexpr (L >= 16) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true));   // row_mirror
                 if constexpr (L == 32) s += __shfl_xor(s, 16);          // the neighbouring row of 16 lanes (integers: any order of additions is exact)
+                }
                 if (pos[u] < p.cap) {                                 // (~0 for idle lanes and groups)
                     const uint32_t row = loc[u];
                     const float dist = fmaf(-2.f, s, sA[2 * row] + bnv[u]);
@@ -1195,7 +1217,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #else
                 constexpr bool abl_exact = false;
 #endif
-                pend16_flush<D, MT, NJ, TN>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : buf_cur, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ, TN, I8>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : buf_cur, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
