@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak = fp32 vector peak
 BF16_MATRIX_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: BF16 MFMA dense peak (spec, without 2:1 sparsity)
+I8_MATRIX_PEAK_TOPS = 5000.0    # MI355X_MICROARCH.md: I8 MFMA = the BF16 cycles at twice the depth
 
 N_RING, LIMBS = 8192, 4
 MODULI = [0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001]   # SEAL BFVDefault(8192) data primes
@@ -338,6 +339,7 @@ def main():
     flat = pf.FlatL2(xb, dev)
     flat.reserve(B, TOPK)
     exact16_active = flat.operands16() == 2            # the bf16 tiles run for every batch size once the base passed the exactness check
+    int8_active = exact16_active and flat.operands8()  # ... and the int8 tiles when every value is an integer in [0, 255] (checked on the device)
     del xb
     # with a process group: the selection kernel writes this rank's packed block IN PLACE into `gathered`, then ONE all-gather
     gathered = torch.empty((world * B, TOPK, 3), dtype=torch.int32, device=dev) if dist else None
@@ -505,6 +507,12 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
         variants = {"uint8_valued_k100_ms": timed_search(flat, xq, 100)}
+        if int8_active and D_last is not None:               # the same data through the bf16 tiles (any exactly representable data runs there)
+            flat.operands8(0)
+            variants["uint8_valued_k200_bf16_operands_ms"] = timed_search(flat, xq, TOPK)
+            Df, If = flat.search(xq, TOPK)
+            variants["bf16_operands_bit_identical_to_timed_path"] = bool(torch.equal(If, I_last) and torch.equal(Df.view(torch.int32), D_last.view(torch.int32)))
+            flat.operands8(1)
         if flat.exact16() and D_last is not None:            # the same data through fp32 operands (what N(0,1) data always runs)
             flat.exact16(0)
             variants["uint8_valued_k200_fp32_operands_ms"] = timed_search(flat, xq, TOPK)
@@ -613,7 +621,8 @@ def main():
             "value": total_q / (elapsed / args.steps), "unit": "encrypted queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 residues (exact-FP64 butterflies) + f32 distances" + (" (bf16 operands, exact on this data)" if exact16_active else ""),
+            "dtype": "u64 residues (exact-FP64 butterflies) + f32 distances" + (" (int8 operands, int32 accumulation: exact on this 8-bit data)" if int8_active else
+                                                                                  " (bf16 operands, exact on this data)" if exact16_active else ""),
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": f"BASELINE config 3 per GPU: flat-L2 top-{TOPK} pre-filter of {B} queries over {args.nb} x {DIM} fp32 "
                                    f"+ fused ct x pt (N=8192, 4 limbs, batch {B}, coefficient form in and out)"
@@ -629,6 +638,14 @@ def main():
             "reference_queries_per_s_at_4_ctpt_each": total_q / ((ms_a + 4 * ms_b + ms_c) * 1e-3),
             "roofline": roofline_block(B, ms_b, sustained_ms),
             "roofline_prefilter": (
+                {"kernel": "k_l2_tile16 (int8 walk; + k_select, k_rows_prep), whole stage", "bound": "mfma", "achieved": tf, "peak": I8_MATRIX_PEAK_TOPS,
+                 "unit": "TOP/s", "frac": tf / I8_MATRIX_PEAK_TOPS, "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b,
+                 "operands": "int8 (value - 128) with int32 accumulation, v_mfma_i32_32x32x32_i8: every value of base and queries is an integer in [0, 255] (checked on the "
+                             "device, value by value; anything else runs the bf16 tiles), thresholds are integers in the accumulators' initial values, survivors "
+                             "are evaluated exactly (v_dot4_u32_u8): (D, I) equal the fp32-operand path's and the bf16 tiles' bit for bit "
+                             "(prefilter_variants.fp32_operands_bit_identical_to_timed_path, .bf16_operands_bit_identical_to_timed_path)",
+                 "frac_of_bf16_matrix_peak_for_reference": tf / BF16_MATRIX_PEAK_TF, "frac_of_fp32_matrix_peak_for_reference": tf / F32_MATRIX_PEAK_TF}
+                if int8_active else
                 {"kernel": "k_l2_tile16 (+ k_select, k_rows_prep), whole stage", "bound": "mfma", "achieved": tf, "peak": BF16_MATRIX_PEAK_TF,
                  "unit": "TFLOP/s", "frac": tf / BF16_MATRIX_PEAK_TF, "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b,
                  "operands": "bf16 with fp32 accumulation: every value of base and queries is an integer of magnitude <= 256 (checked on the device, "

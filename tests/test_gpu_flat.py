@@ -426,6 +426,85 @@ def test_exact16_path_is_bit_identical_on_integer_data(d, nq, k):
         assert np.allclose(got16[0], Dr, rtol=RTOL, atol=0) and (np.sort(got16[1], axis=1) == np.sort(Ir, axis=1)).mean() > 0.99
 
 
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 60000, 300, 200), (64, 40000, 129, 10), (32, 30000, 257, 100), (96, 50000, 513, 64), (128, 9000, 1024, 1024),
+                                       (128, 200000, 70, 1)])
+def test_int8_tiles_are_bit_identical_on_8bit_data(d, nb, nq, k):
+    """8-bit data (integers in [0, 255], SIFT's range): the int8 matrix instruction with integer thresholds against the bf16 tiles on the same
+    data, the fp32-operand loop and the oracle -- bit for bit, with the extreme values, plateaus of ties and duplicates of queries in the base"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(d * 7 + nq)
+    xb = rng.integers(0, 256, (nb, d)).astype(np.float32)
+    xq = rng.integers(0, 256, (nq, d)).astype(np.float32)
+    xb[:40] = 255.0; xb[40:80] = 0.0; xq[0] = 0.0; xq[1] = 255.0        # largest products and sums, both signs of (value - 128)
+    xb[100:400] = xb[100]                                                 # a plateau of ties
+    xb[9000 - 50:9000 - 40] = xq[2]                                       # exact hits (distance 0) behind the bootstrap chunk
+    dev = _dev()
+    f = pf.FlatL2(xb, dev)
+    q = torch.from_numpy(xq).to(dev)
+    assert f.operands8() and f.operands16() == 2
+    D8, I8 = f.search(q, k)
+    assert f.operands8(0) is False and f.operands16() == 2               # bf16 tiles on the same data
+    D16, I16 = f.search(q, k)
+    f.operands16(0)
+    D32, I32 = f.search(q, k)
+    for Dx, Ix in ((D16, I16), (D32, I32)):
+        assert (I8 == Ix).all() and (D8.view(torch.int32) == Dx.view(torch.int32)).all()
+    Dr, Ir = oracle.flat_l2_search(xb, xq[:3], k)
+    assert (I8[:3].cpu().numpy() == Ir).all() and (D8[:3].cpu().numpy() == Dr).all()
+    if k >= 10 and nb > 9000:
+        assert (D8[2, :10].cpu().numpy() == 0).all()
+
+
+def test_int8_tiles_only_where_both_sides_are_8bit():
+    """the int8 image exists only for a base of integers in [0, 255] with d a multiple of 32 up to 128, and a query tile with any value outside
+    that range (negative, 256, a fraction) takes the bf16 tiles inside the same launch -- results identical either way"""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(99)
+    base = rng.integers(0, 256, (30000, 128)).astype(np.float32)
+    assert pf.FlatL2(base, dev).operands8()
+    for bad in (-1.0, 256.0, 0.5):
+        xb = base.copy(); xb[777, 3] = bad
+        assert not pf.FlatL2(xb, dev).operands8()
+    for d in (16, 48, 80, 144, 256):                                      # not whole 32-deep k-steps, or beyond 128
+        assert not pf.FlatL2(rng.integers(0, 256, (1000, d)).astype(np.float32), dev).operands8()
+    f = pf.FlatL2(base, dev)
+    xq = rng.integers(0, 256, (640, 128)).astype(np.float32)             # five query tiles: 0 and 3 stay 8-bit
+    xq[130, 5] = -3.0; xq[300, 77] = 256.0; xq[600, 0] = 0.25            # tiles 1, 2 (exact, not 8-bit) and 4 (inexact: filter + fp32 chain)
+    q = torch.from_numpy(xq).to(dev)
+    D8, I8 = f.search(q, 100)
+    f.operands8(0)
+    D16, I16 = f.search(q, 100)
+    f.operands16(0)
+    D32, I32 = f.search(q, 100)
+    for Dx, Ix in ((D16, I16), (D32, I32)):
+        assert (I8 == Ix).all() and (D8.view(torch.int32) == Dx.view(torch.int32)).all()
+    rows = [0, 130, 300, 500]
+    Dr, Ir = oracle.flat_l2_search(base, xq[rows], 100)
+    assert (I8[rows].cpu().numpy() == Ir).all() and (D8[rows].cpu().numpy() == Dr).all()
+
+
+def test_int8_tiles_dense_survivors_and_overflow():
+    """base rows ordered by DEcreasing distance to every query (every streamed row passes the integer threshold: lists overflow into the exact rescan,
+    flushes in mid-walk), and thresholds at both ends of the int32 range of the row half"""
+    import prefhetch_amd as pf
+    nb, nq, k, d = 40000, 200, 100, 128
+    m = (np.arange(nb)[::-1] * (d + 1) // nb)
+    xb = (np.arange(d)[None, :] < m[:, None]).astype(np.float32) * 255.0
+    rng = np.random.default_rng(5)
+    xq = rng.integers(0, 2, (nq, d)).astype(np.float32)
+    dev = _dev()
+    f = pf.FlatL2(xb, dev)
+    assert f.operands8()
+    q = torch.from_numpy(xq).to(dev)
+    D8, I8 = f.search(q, k)
+    f.operands16(0)
+    D32, I32 = f.search(q, k)
+    assert (I8 == I32).all() and (D8.view(torch.int32) == D32.view(torch.int32)).all()
+    Dr, Ir = oracle.flat_l2_search(xb, xq[:4], k)
+    assert (I8[:4].cpu().numpy() == Ir).all() and (D8[:4].cpu().numpy() == Dr).all()
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_exact16_dense_survivors_and_far_thresholds(d):
     """bf16 tiles under stress: base rows ordered by DEcreasing distance (every streamed row passes the filter: the verdict words are

@@ -35,15 +35,20 @@ for it in range(iters):
     xb, xq = np.ascontiguousarray(xb, np.float32), np.ascontiguousarray(xq, np.float32)
     f = pf.FlatL2(xb, dev)
     q = torch.from_numpy(xq).to(dev)
-    mode = f.operands16()
+    mode, m8 = f.operands16(), f.operands8()
     D1, I1 = f.search(q, k)
+    ok = True
+    if m8:                                                    # int8 tiles ran: the bf16 tiles on the same data too
+        f.operands8(0)
+        D2, I2 = f.search(q, k)
+        ok = bool((I1 == I2).all() and (D1.view(torch.int32) == D2.view(torch.int32)).all())
     f.operands16(0)
     D0, I0 = f.search(q, k)
-    ok = bool((I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all())
+    ok = ok and bool((I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all())
     if ok and law in ("int", "ties", "neg", "dups"):
         Dr, Ir = oracle.flat_l2_search(xb, xq[:2], k)
         ok = bool((I1[:2].cpu().numpy() == Ir).all() and (D1[:2].cpu().numpy() == Dr).all())
-    print("%3d nb=%6d nq=%4d k=%4d d=%3d %-5s operands16=%d %s" % (it, nb, nq, k, d, law, mode, "ok" if ok else "MISMATCH"), flush=True)
+    print("%3d nb=%6d nq=%4d k=%4d d=%3d %-5s operands16=%d int8=%d %s" % (it, nb, nq, k, d, law, mode, m8, "ok" if ok else "MISMATCH"), flush=True)
     bad += not ok
     del f
 print("fuzz:", "all ok" if not bad else "%d MISMATCHES" % bad)
