@@ -614,6 +614,7 @@ struct Pend16 {
     uint8_t loc[CAP];                  // local query row
     uint32_t rcnt[128], rbase[128];
     uint32_t n;
+    uint32_t wcnt[2][4];               // verdict records each wave holds, by tile parity (the int8 walk's rings)
 };
 
 #ifdef PF_FLAT_STAMPS        // experiments (tools/flat_stamps.py): s_memtime at the phase boundaries of the tile walk
@@ -653,10 +654,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (define
 #else
 #define PF_FLUSH_INLINE __forceinline__
 #endif
-template <int D, int MT, int NJ, int TN, bool I8 = false>
+// RING: the verdict words come from this wave's ring of records in LDS instead (the int8 walk appends a (word, tile, column block, lane) record per
+// non-zero word as the tile ends -- a ballot and an LDS write, no barrier -- and calls this only when a ring is nearly full or the walk ends:
+// the parking above cost a quarter of the int8 walk's time); rc records, ct_base = the walk's first tile.
+template <int D, int MT, int NJ, int TN, bool I8 = false, bool RING = false>
 __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
-                                             uint32_t flush_no = 0) {
+                                             uint32_t flush_no = 0, const uint2 *ring = nullptr, uint32_t rc = 0) {
     (void)flush_no;
     using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
     // lanes per survivor: LU = D / 8 of them hold 16 bytes of both rows each, rounded up to a power of two (L) for the DPP sum
@@ -664,10 +668,13 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
     constexpr uint32_t LU = I8 ? D / 16 : D / 8, L = LU <= 2 ? 2 : LU <= 4 ? 4 : LU <= 8 ? 8 : LU <= 16 ? 16 : 32, G = 256 / L;         // G survivors per pass
     const int lane = tid & 63;
     uint32_t left = 0;
+    if constexpr (!RING) {
 #pragma unroll
-    for (int u = 0; u < MT; ++u)
+        for (int u = 0; u < MT; ++u)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
+            for (int jj = 0; jj < NJ; ++jj) left += __popc(surv[u][jj]);
+    }
+    uint32_t cur = 0, meta = 0, rb = 0;                               // RING: what is left of this lane's current record; the next batch of 64 records
     PF_FLSTAMP(0);
     // Parking (LDS only) happens at every call; the expensive part -- barriers, a returning global atomic per row, the rows of
     // every survivor fetched again -- only once the list is long (HIGH), overflowed (a lane could not park everything), or the
@@ -675,6 +682,39 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
     // memory per walk instead of one per MT tiles (the flushes were 35 % of the tile kernels' time: profiles/r03_flat_ablation.txt).
     for (;;) {
         PF_FLSTAMP(1);
+        if constexpr (RING) {
+            // batches of 64 records, a record per lane, until the ring is empty or the list is full (a lane could not park every bit of its record)
+            for (;;) {
+                if (__ballot(cur != 0) == 0) {
+                    if (rb >= rc) break;                                 // wave-uniform
+                    const uint32_t idx = rb + (uint32_t)lane;
+                    const uint2 rec = idx < rc ? ring[idx] : make_uint2(0u, 0u);
+                    cur = rec.x; meta = rec.y;
+                    rb += 64;
+                }
+                const uint32_t cnt = (uint32_t)__popc(cur);
+                const uint32_t incl = wave_incl_scan(cnt);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);      // > 0: some lane holds a record
+                uint32_t slot = 0;
+                if (lane == 0) slot = atomicAdd(&pd.n, tot);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot) + incl - cnt;
+                uint32_t take = slot < Pend16::CAP ? Pend16::CAP - slot : 0u;
+                take = cnt < take ? cnt : take;
+                const uint32_t ls = meta & 63u, jj = (meta >> 6) & 3u, trel = meta >> 8;
+                while (take) {                                           // highest set bit first (a lane rarely holds more than one)
+                    const int b = 31 - __builtin_clz(cur);
+                    cur &= ~(1u << b);
+                    const int sb = 31 - b, r = sb & 15;
+                    const uint32_t lrow = (uint32_t)(wm + 2 * (sb & 16) + (r & 3) + 8 * (r >> 2) + 4 * (ls >> 5));
+                    pd.id[slot] = (uint32_t)(p.nb_first + (size_t)(ct_base + trel) * TN + wn + 32 * jj + (ls & 31u));
+                    pd.loc[slot] = (uint8_t)lrow;
+                    atomicAdd(&pd.rcnt[lrow], 1u);
+                    ++slot; --take;
+                }
+                if (__ballot(cur != 0)) break;                           // the list is full
+            }
+            left = (cur != 0 || rb < rc) ? 1u : 0u;
+        } else {
         // slots: ONE returning LDS atomic per wave (a prefix sum over the lanes' counts), not one per lane with survivors
         const uint32_t incl = wave_incl_scan(left);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -739,6 +779,7 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 surv[u][jj] = m;
             }
         }
+        }   // (!RING)
         PF_FLSTAMP(2);
         const bool any_left = __syncthreads_or(left != 0) != 0;          // (the barrier: everything parked is visible)
         PF_FLSTAMP(3);
@@ -1093,6 +1134,15 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
     survx sv;
 #pragma unroll
     for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
+    // The int8 walk keeps its verdict words in LDS instead: its two column tiles leave room behind them in the tile buffers of the kernel (sized for
+    // the bf16 tiles) for a ring of (word, tile, column block, lane) records per wave, appended to as a tile ends and decoded when a ring is nearly
+    // full or the walk ends -- one call of pend16_flush per walk in the long chunks instead of one per MT tiles.
+    constexpr size_t SMEM16 = 2 * (size_t)TN * (D + AUX16) * 2 > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * (D + AUX16) * 2 : F32_TILE_LDS<GEO>;
+    constexpr uint32_t RING_ROOM = I8 ? (uint32_t)((SMEM16 - 2 * (size_t)TN * PITCH) / (4 * sizeof(uint2))) : 0u;
+    constexpr uint32_t RCAP = RING_ROOM >= 1024 ? 1024u : RING_ROOM >= 512 ? 512u : 256u;          // records per wave
+    static_assert(!I8 || (RING_ROOM >= 256 && NJ * 64 <= 128), "a ring takes at least two tiles' worth of records");
+    uint2 *const ring = reinterpret_cast<uint2 *>(smem + 2 * (size_t)TN * PITCH) + (size_t)wave * RCAP;
+    uint32_t rc = 0;                                                  // records in this wave's ring (wave-uniform)
     for (uint32_t ct = ct0; ct < ct1; ++ct) {
         const uint32_t u = (ct - ct0) % MT, cur = (ct - ct0) & 1u;
         char *const buf_cur = cur ? sB16_1 : sB16_0, *const buf_nxt = cur ? sB16_0 : sB16_1;
@@ -1191,8 +1241,19 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #ifdef PF_ABL_NOSURV   // ablation (timing only, wrong results): the verdicts are computed and dropped -- nothing to flush
             for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj] & (p.nq == 0xFFFFFFFFu ? ~0u : 0u);
 #else
-            for (int jj = 0; jj < NJ; ++jj) sv[u * NJ + jj] = s1[jj];   // wave-uniform index: v_movreld
+            for (int jj = 0; jj < NJ; ++jj) {
+                if constexpr (I8) {
+                    const uint64_t m = __ballot(s1[jj] != 0);
+                    if (m) {                                            // wave-uniform
+                        if (s1[jj]) ring[rc + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_uint2(s1[jj], ((ct - ct0) << 8) | ((uint32_t)jj << 6) | (uint32_t)lane);
+                        rc += (uint32_t)__popcll(m);
+                    }
+                } else {
+                    sv[u * NJ + jj] = s1[jj];                           // wave-uniform index: v_movreld
+                }
+            }
 #endif
+            if constexpr (I8) { if (lane == 0) pend.wcnt[(ct - ct0) & 1u][wave] = rc; }      // (read after the tile's barrier)
             PF_FSTAMP(4);
         } else {
             // q0 made opaque per tile: otherwise hipcc hoists the row addresses of the slab stores out of the tile loop
@@ -1205,7 +1266,16 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
         __syncthreads();                                                // the tile's one barrier: the other buffer is complete
 #endif
         PF_FSTAMP(5);
-        if constexpr (FILTER) {
+        if constexpr (I8) {
+            const uint32_t *wc = pend.wcnt[(ct - ct0) & 1u];
+            const uint32_t c01 = wc[0] > wc[1] ? wc[0] : wc[1], c23 = wc[2] > wc[3] ? wc[2] : wc[3];
+            const bool full = (c01 > c23 ? c01 : c23) > RCAP - 128;      // a tile adds at most 128 records to a ring
+            if (full || ct + 1 == ct1) {                                // workgroup-uniform (every wave read the same four counts)
+                uint32_t none[MT][NJ] = {};
+                pend16_flush<D, MT, NJ, TN, true, true>(p, pend, stage, q0, tid, none, ct0, wm, wn, false, nullptr, q_valid, ct + 1 == ct1, 0, ring, rc);
+                rc = 0;
+            }
+        } else if constexpr (FILTER) {
             if (u == MT - 1 || ct + 1 == ct1) {                         // workgroup-uniform
                 uint32_t surv[MT][NJ];
 #pragma unroll
