@@ -1312,6 +1312,9 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     if constexpr (FILTER && D % 32 == 0 && D <= 128) {
         if (p.xb8 && !(qflags & 7u)) { tile16_walk<true, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags); return; }
     }
+#ifdef PF_ABL_I8ONLY   // experiment (register count of the int8 walk on its own; other query tiles are not processed: wrong results for them)
+    if constexpr (!(FILTER && D % 32 == 0 && D <= 128))
+#endif
     tile16_walk<FILTER, D, false>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
 }
 
