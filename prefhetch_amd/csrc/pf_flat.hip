@@ -1517,7 +1517,7 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
     }
     const uint32_t prefix = radix_kth<THREADS, VPT>(u, n, k, hist, ctl, tid);
     // prefix = bit pattern of the k-th smallest distance; count what is below / equal
-    if (tid == 0) { ctl[2] = 0; }
+    if (tid == 0) { ctl[2] = 0; ctl[3] = prefix; }
     __syncthreads();
     uint32_t take = 0;
 #pragma unroll
@@ -1592,6 +1592,14 @@ __device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
     bool done = false;
     if (p.mode == 0 && c0 == 0 && p.nb_count > k && p.nb_count <= 8192)               // first chunk, more rows than results
         done = radix_bootstrap<THREADS>(keys, cnt, hist, ctl, k, p.slab + q * (size_t)p.slab_ld, p.nb_first, (uint32_t)p.nb_count, tid);
+    // Batches (256 threads: every later merge is merge_wave or the full sort of the last chunk, neither assumes an ordered state): when exactly k keys came
+    // back -- no ties at the k-th distance to cut by id -- the bootstrap's state goes out as it is, unsorted; the sort below was 6 of this kernel's 30 us.
+    // (Inexact operands keep it: the density estimate below reads the sorted keys.)
+    if (THREADS == 256 && done && !p.last && cnt == k && !(p.q_flags && (!p.base_exact || (p.q_flags[q / 128] & 1u)))) {     // workgroup-uniform
+        for (uint32_t i = tid; i < k; i += THREADS) p.state[q * k + i] = keys[i];
+        if (tid == 0) { p.state_cnt[q] = k; p.tau[q] = __uint_as_float(ctl[3]); p.cand_cnt[q] = 0; }
+        return;
+    }
     if (p.mode == 0 && !done) {
         const float *row = p.slab + q * (size_t)p.slab_ld;
         const bool vec = (p.slab_ld & 3) == 0;
