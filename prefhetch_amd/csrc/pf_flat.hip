@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             for (uint32_t k = 0; k < d; ++k) sy += (int)row[k] - 128;
             const int Cc = (int)acc - 256 * sy;
             u32x4 w;
-            w[0] = (uint32_t)(-(Cc >> 1)); w[1] = 0; w[2] = 0; w[3] = 0;
+            w[0] = (uint32_t)(-(Cc >> 1)); w[1] = (uint32_t)sy; w[2] = 0; w[3] = 0;      // (sum y' for the unfiltered launch, which forms distances)
             *reinterpret_cast<u32x4 *>(x8 + (r0 + lane) * (size_t)pitch8 + d) = w;   // 16-byte aligned: d and pitch8 are multiples of 16
         }
     }
@@ -978,7 +978,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
     constexpr int TM = GEO::TM, TN = GEO::TN, MI = GEO::MI, NJ = GEO::NJ, PITCH = I8 ? D + AUX8 : (D + (int)AUX16) * 2;
     constexpr int KS = I8 ? 32 : 16, STEPS = D / KS;                 // depth of a matrix instruction, k-steps of a tile
     constexpr uint32_t PIECES = TN * PITCH / 16, SWEEPS = PIECES / 256, REM = PIECES % 256;      // 16-byte pieces of a column tile: D = 128: 8 x 256 + 128
-    static_assert(PITCH % 32 == 16 && (TN == 128 || TN == 64) && TM == 128 && D % KS == 0 && (!I8 || FILTER), "odd row pitch in 16-byte units; 128 x 128 or 128 x 64 tiles");
+    static_assert(PITCH % 32 == 16 && (TN == 128 || TN == 64) && TM == 128 && D % KS == 0, "odd row pitch in 16-byte units; 128 x 128 or 128 x 64 tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if constexpr (FILTER) {
         if (tid < TM) pend.rcnt[tid] = 0;
@@ -1082,6 +1082,16 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
                 reinterpret_cast<int *>(stage)[3 * TM + tid] = r0;
             }
         }
+    } else if constexpr (I8) {
+        // the unfiltered (bootstrap) launch forms distances: x.y = S + 128 (sum x' + sum y') + 16384 d -- the row's sum here, the column's behind its row
+        if (tid < TM) {
+            const uint32_t r = (uint32_t)tid < q_valid ? (uint32_t)tid : q_valid - 1;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p.xq8 + (q0 + r) * (size_t)D);
+            int sx = 0;
+#pragma unroll 8
+            for (int t = 0; t < D / 4; ++t) sx = __builtin_amdgcn_sdot4((int)w[t], 0x01010101, sx, false);
+            reinterpret_cast<int *>(stage)[3 * TM + tid] = 128 * sx + 16384 * D;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1171,7 +1181,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
         // itself hipcc hoists every fragment read of the tile to the top)
         const char *fbx = buf_cur + (wn + (lane & 31)) * PITCH, *fb = fbx + (lane >> 5) * 16;
         f32x16 acc[MI][NJ];
-        if constexpr (I8) {                                          // the thresholds' halves instead of zero: row half from registers, column half behind the row
+        if constexpr (I8 && FILTER) {                                // the thresholds' halves instead of zero: row half from registers, column half behind the row
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 const int c0v = *reinterpret_cast<const int *>(fbx + 32 * jj * PITCH + D);
@@ -1233,6 +1243,19 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux[i], b[c][jj], acc[i][jj], 0, 0, 0);
         }
+        if constexpr (I8 && !FILTER) {                               // integer S -> x.y as fp32 (below 2^24: exact), what the epilogue expects
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int syv = 128 * *reinterpret_cast<const int *>(fbx + 32 * jj * PITCH + D + 4);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float bits = acc[i][jj][r];               // through a scalar: __builtin_bit_cast applied to the vector element itself reads element 0 (hipcc 7.2)
+                        acc[i][jj][r] = (float)(__float_as_int(bits) + r0v[i][r] + syv);
+                    }
+            }
+        }
         PF_FSTAMP(3);
         if constexpr (FILTER) {
             uint32_t s1[NJ];
@@ -1266,7 +1289,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
         __syncthreads();                                                // the tile's one barrier: the other buffer is complete
 #endif
         PF_FSTAMP(5);
-        if constexpr (I8) {
+        if constexpr (I8 && FILTER) {
             const uint32_t *wc = pend.wcnt[(ct - ct0) & 1u];
             const uint32_t c01 = wc[0] > wc[1] ? wc[0] : wc[1], c23 = wc[2] > wc[3] ? wc[2] : wc[3];
             const bool full = (c01 > c23 ? c01 : c23) > RCAP - 128;      // a tile adds at most 128 records to a ring
@@ -1309,11 +1332,11 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     const uint32_t qflags = p.q_inexact[qt];                        // workgroup-uniform
     // 8-bit data on both sides (the base's image exists only then; bit 2 of the tile's word: a query value outside [0, 255]; bit 1: its
     // lists overflowed, fp32 tiles from then on): the int8 matrix instruction.  Anything else: bf16 operands.
-    if constexpr (FILTER && D % 32 == 0 && D <= 128) {
-        if (p.xb8 && !(qflags & 7u)) { tile16_walk<true, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags); return; }
+    if constexpr (D % 32 == 0 && D <= 128) {
+        if (p.xb8 && !(qflags & 7u)) { tile16_walk<FILTER, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags); return; }
     }
 #ifdef PF_ABL_I8ONLY   // experiment (register count of the int8 walk on its own; other query tiles are not processed: wrong results for them)
-    if constexpr (!(FILTER && D % 32 == 0 && D <= 128))
+    if constexpr (!(D % 32 == 0 && D <= 128))
 #endif
     tile16_walk<FILTER, D, false>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
 }
