@@ -34,7 +34,7 @@ ok = s[..., 0] > 0
 nt = int(ok[0, 0].sum())
 print("tiles stamped per workgroup:", nt)
 s = s[:, :, :nt]
-names = ["LDS-DMA requests for tile t+1", "addresses, zero acc", "fragment reads + 36 MFMA", "sign sweep", "vmcnt(0) + barrier"]
+names = ["LDS-DMA requests for tile t+1", "addresses, zero acc", "fragment reads + matrix instructions", "sign sweep", "vmcnt(0) + barrier"]
 for k in range(K - 1):
     d = s[..., k + 1] - s[..., k]
     print("%-40s mean %8.0f  p50 %8.0f  max %8.0f" % (names[k], d.mean(), np.median(d), d.max()))
