@@ -781,6 +781,9 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
         }
         }   // (!RING)
         PF_FLSTAMP(2);
+#ifdef PF_ABL_NOEMIT   // ablation (timing only, wrong results): the list is built and dropped
+        if constexpr (RING) { __syncthreads(); if (tid == 0) pd.n = 0; if (tid < 128) pd.rcnt[tid] = 0; __syncthreads(); if (__syncthreads_or(left != 0) == 0) return; continue; }
+#endif
         const bool any_left = __syncthreads_or(left != 0) != 0;          // (the barrier: everything parked is visible)
         PF_FLSTAMP(3);
         const uint32_t have = pd.n;
@@ -1295,7 +1298,9 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
             const bool full = (c01 > c23 ? c01 : c23) > RCAP - 128;      // a tile adds at most 128 records to a ring
             if (full || ct + 1 == ct1) {                                // workgroup-uniform (every wave read the same four counts)
                 uint32_t none[MT][NJ] = {};
+#ifndef PF_ABL_NODRAIN   // ablation (timing only, wrong results): the records are appended and dropped
                 pend16_flush<D, MT, NJ, TN, true, true>(p, pend, stage, q0, tid, none, ct0, wm, wn, false, nullptr, q_valid, ct + 1 == ct1, 0, ring, rc);
+#endif
                 rc = 0;
             }
         } else if constexpr (FILTER) {
