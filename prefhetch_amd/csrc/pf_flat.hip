@@ -649,11 +649,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);       // (define
 #ifndef PF_APPROX_UNROLL2
 #define PF_APPROX_UNROLL2 4     // ... both rows from memory
 #endif
-#if PF_B16_TN == 64
 #define PF_FLUSH_INLINE __forceinline__
-#else
-#define PF_FLUSH_INLINE __forceinline__
-#endif
 // RING: the verdict words come from this wave's ring of records in LDS instead (the int8 walk appends a (word, tile, column block, lane) record per
 // non-zero word as the tile ends -- a ballot and an LDS write, no barrier -- and calls this only when a ring is nearly full or the walk ends:
 // the parking above cost a quarter of the int8 walk's time); rc records, ct_base = the walk's first tile.
@@ -1310,7 +1306,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
                 // (both tile buffers are free for the flush once no tile follows: nothing is in flight into them, nobody reads them; in mid-walk the
                 // buffer of the tile just finished is -- its readers passed the barrier above, the next request into it comes with the next tile)
-                #ifdef PF_ABL_EXACTFLUSH   // ablation (timing only, wrong results on inexact data): survivors by the 16-bit dot products whatever the operands
+#ifdef PF_ABL_EXACTFLUSH   // ablation (timing only, wrong results on inexact data): survivors by the 16-bit dot products whatever the operands
                 constexpr bool abl_exact = true;
 #else
                 constexpr bool abl_exact = false;
