@@ -49,6 +49,9 @@ typedef void *pf_stream;          /* hipStream_t */
 
 const char *pf_status_str(pf_status s);
 const char *pf_last_error(void);
+/* "" for the product build; otherwise the extra compiler flags the library was built with, prefixed "experiment:" when one of them
+ * is a timing-only ablation or debug switch (such a library returns wrong results and must never be shipped) */
+const char *pf_build_flags(void);
 pf_status pf_device_count(int *count);
 
 /* ---- device memory helpers, so that a host written without HIP headers can own buffers ---------- */

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PREFHETCH_HIP_LIB") or os.path.join(_HERE, "lib", "li
 
 # every symbol include/prefhetch_hip.h declares
 SYMBOLS = [
-    "pf_status_str", "pf_last_error", "pf_device_count",
+    "pf_status_str", "pf_last_error", "pf_build_flags", "pf_device_count",
     "pf_malloc", "pf_free", "pf_memcpy_h2d", "pf_memcpy_d2h", "pf_memcpy_d2d", "pf_stream_synchronize",
     "pf_ctx_create", "pf_ctx_destroy", "pf_ctx_info", "pf_ctx_force_u64",
     "pf_ntt_forward", "pf_ntt_inverse", "pf_ntt_forward_to", "pf_ntt_inverse_to", "pf_dyadic_mul", "pf_poly_add", "pf_poly_sub", "pf_poly_negate",
@@ -41,6 +41,13 @@ def _load():
     lib.pf_status_str.argtypes = [C.c_int32]
     lib.pf_last_error.restype = C.c_char_p
     lib.pf_last_error.argtypes = []
+    lib.pf_build_flags.restype = C.c_char_p
+    lib.pf_build_flags.argtypes = []
+    flags = (lib.pf_build_flags() or b"").decode()
+    if flags.startswith("experiment:") and not os.environ.get("PREFHETCH_HIP_LIB"):
+        # a timing-only ablation / debug build (pf_common.hpp) may only be loaded when it was asked for by path
+        raise ImportError(f"prefhetch_amd: {LIB_PATH} is an experiment build ({flags}); it returns wrong results. "
+                          "Rebuild with a plain `make -C prefhetch_amd/csrc`, or name it in PREFHETCH_HIP_LIB on purpose.")
     lib.pf_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.pf_malloc.argtypes = [i32, C.POINTER(vp), sz]
     lib.pf_free.argtypes = [i32, vp]
@@ -100,7 +107,7 @@ def _load():
     lib.pf_ivfpq_search_lists.argtypes = [vp, vp, vp, sz, u32, vp, vp, sz, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
-        if name not in ("pf_status_str", "pf_last_error"):
+        if name not in ("pf_status_str", "pf_last_error", "pf_build_flags"):
             fn.restype = C.c_int32
     return lib
 

@@ -4,6 +4,19 @@
 #include <string>
 #include "../../include/prefhetch_hip.h"
 
+
+// Experiment switches.  Every PF_ABL_* macro builds a library that returns WRONG RESULTS (timing-only ablations), PF_FLAT_STAMPS one that
+// writes phase stamps into a debug buffer: such a build must say so (-DPF_EXPERIMENT_BUILD), goes to its own object directory (the
+// Makefile hashes $(EXTRA) into BUILD), reports itself through pf_build_flags() and is refused by the Python loader unless it was
+// asked for by path (PREFHETCH_HIP_LIB).  A default `make` can therefore never link an ablation object into lib/libprefhetch_hip.so.
+#if defined(PF_ABL_NOEMIT) || defined(PF_ABL_NODMA) || defined(PF_ABL_NOSURV) || defined(PF_ABL_NOBAR) || defined(PF_ABL_NODRAIN) || \
+    defined(PF_ABL_EXACTFLUSH) || defined(PF_ABL_I8ONLY) || defined(PF_FLAT_STAMPS) || defined(PF_DEV_ONLY_D128)
+#define PF_HAS_EXPERIMENT_SWITCH 1
+#ifndef PF_EXPERIMENT_BUILD
+#error "PF_ABL_* / PF_FLAT_STAMPS are experiment switches (wrong results / debug buffers): add -DPF_EXPERIMENT_BUILD and build into a directory of its own"
+#endif
+#endif
+
 namespace pf {
 
 std::string &last_error_ref();

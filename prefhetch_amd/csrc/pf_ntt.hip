@@ -125,6 +125,19 @@ const char *pf_status_str(pf_status s) {
 
 const char *pf_last_error(void) { return last_error_ref().c_str(); }
 
+// what this library was built with: "" for the product build; the Makefile's $(EXTRA) otherwise, prefixed "experiment:" when the
+// build carries a switch that changes results or adds debug buffers (pf_common.hpp)
+#ifndef PF_BUILD_EXTRA
+#define PF_BUILD_EXTRA ""
+#endif
+const char *pf_build_flags(void) {
+#ifdef PF_EXPERIMENT_BUILD
+    return "experiment: " PF_BUILD_EXTRA;
+#else
+    return PF_BUILD_EXTRA;
+#endif
+}
+
 pf_status pf_device_count(int *count) {
     if (!count) return fail(PF_ERR_INVALID_ARG, "null argument");
     int n = 0;

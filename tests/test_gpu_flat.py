@@ -144,6 +144,7 @@ def test_config3_prefilter_full_size(pf):
     xb = rng.integers(0, 256, (nb, 128), dtype=np.uint8).astype(np.float32)
     xq = rng.integers(0, 256, (nq, 128), dtype=np.uint8).astype(np.float32)
     idx = pf.FlatL2(xb, _dev())
+    assert idx.operands8() and idx.operands16() == 2        # the path the benchmark times: int8 tiles (a silent switch-off must not stay green)
     dq = torch.from_numpy(xq).to(_dev())
     D, I = idx.search(dq, k)
     assert bool((D[:, 1:] >= D[:, :-1]).all())

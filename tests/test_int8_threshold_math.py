@@ -16,11 +16,18 @@ def test_int8_threshold_init_is_conservative_and_tight(d):
     xp, yp = x - 128, y - 128
     S = xp @ yp.T
     assert (x @ y.T == S + 128 * (xp.sum(1)[:, None] + yp.sum(1)[None, :]) + 16384 * d).all()      # what the unfiltered launch adds back
-    for tau_kind in ("typical", "tight", "zero"):
+    for tau_kind in ("typical", "tight", "zero", "fractional"):
         if tau_kind == "typical":
             tau = np.sort(dist, axis=1)[:, 200]                            # a k-th distance: ties with it exist
         elif tau_kind == "tight":
             tau = np.sort(dist, axis=1)[:, 1] + 1
+        elif tau_kind == "fractional":
+            # a threshold that is not an integer (no caller produces one today: every distance on this path is an integer below 2^24;
+            # the device rounds UP -- (int)ceilf(tau) -- so that the filter stays a superset whatever tau it is handed)
+            tau_f = np.sort(dist, axis=1)[:, 200].astype(np.float64) + 0.5
+            assert ((dist <= tau_f[:, None]) == (dist <= np.ceil(tau_f)[:, None])).all()        # integers: ceil keeps the set
+            assert ((dist <= tau_f[:, None]) != (dist <= np.trunc(tau_f)[:, None] - 1)).any()
+            tau = np.ceil(tau_f).astype(np.int64)
         else:
             tau = np.zeros(nq, np.int64)
         R = (x * x).sum(1) - tau - 256 * xp.sum(1) - 32768 * d             # row half

@@ -16,7 +16,7 @@ done
 bash tools/pmc_flat.sh ${tag}_flat 3 1024 > $O/${tag}_pmc_flat_tiles.txt 2>&1
 # phase stamps need a library built with -DPF_FLAT_STAMPS: built HERE, from this snapshot's sources, into /tmp (never a stale
 # library carried along in the tree)
-if make -C prefhetch_amd/csrc -j16 BUILD=/tmp/pf_build_stamps OUT=/tmp/pf_stamps/libprefhetch_hip.so EXTRA=-DPF_FLAT_STAMPS /tmp/pf_stamps/libprefhetch_hip.so > $O/${tag}_stamps_build.log 2>&1; then
+if make -C prefhetch_amd/csrc -j16 BUILD=/tmp/pf_build_stamps OUT=/tmp/pf_stamps/libprefhetch_hip.so EXTRA="-DPF_EXPERIMENT_BUILD -DPF_FLAT_STAMPS" /tmp/pf_stamps/libprefhetch_hip.so > $O/${tag}_stamps_build.log 2>&1; then
   PREFHETCH_HIP_LIB=/tmp/pf_stamps/libprefhetch_hip.so python3 tools/flat_stamps.py > $O/${tag}_flat_stamps.txt 2>&1
 fi
 python3 tools/time_flat_gauss.py > $O/${tag}_flat_gaussian.txt 2>&1
