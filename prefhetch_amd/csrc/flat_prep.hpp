@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             u32x4 w;
             w[0] = (uint32_t)(-(Cc >> 1)); w[1] = (uint32_t)sy; w[2] = 0; w[3] = 0;      // (sum y' for the unfiltered launch, which forms distances)
             *reinterpret_cast<u32x4 *>(x8 + (r0 + lane) * (size_t)pitch8 + d) = w;   // 16-byte aligned: d and pitch8 are multiples of 16
-            if (c0f) c0f[frag8_c0_index(r0 + lane)] = -(Cc >> 1);
+            if (c0f) c0f[frag8_c0_index(r0 + lane)] = Cc;                               // C itself: the walk halves it, the flush forms distances with it
         }
         if (x8 && !aux && sx8) {                                 // queries: sum (x - 128), the row half of the integer threshold needs it (tile8_walk)
             int s = 0;

@@ -396,7 +396,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 }
 
 // the filtered int8 walk (flat_tile8.hpp); TILE8_LDS: the LDS its four waves carve out of the kernel's tile buffers
-constexpr size_t TILE8_LDS = 4 * 12288;
+constexpr size_t TILE8_LDS = 4 * 17024;
 template <int D, size_t SMEM_BYTES>
 __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t group, char *smem, float *stage, Pend16 &pend, const uint32_t qt, const uint32_t grp);
 

@@ -31,7 +31,7 @@ using i32x4w = __attribute__((ext_vector_type(4))) int;
 
 // LDS of one wave of the walk (carved out of the kernel's tile buffers, which this walk does not use)
 struct Walk8Lds {
-    static constexpr uint32_t RCAP = 768, LCAP = 1024;                  // verdict records (8 bytes), decoded survivors (4 bytes)
+    static constexpr uint32_t RCAP = 1280, LCAP = 1024;                 // verdict records (8 bytes), decoded survivors (4 bytes)
     uint2 ring[RCAP];
     uint32_t list[LCAP];
     uint32_t rcnt[128], rbase[128];
@@ -53,10 +53,8 @@ struct Walk8 {
 template <int D>
 __device__ __forceinline__ void walk8_flush(const TileArgs &p, Walk8Lds &L, const size_t q0, const uint32_t q_valid, const int lane, const uint32_t rc,
                                             const uint32_t step0) {
-    constexpr int NKS = Walk8<D>::NKS;
     constexpr uint32_t LU = D / 16;                                     // lanes of a group of 8 that hold 16 bytes of both rows
     constexpr int U = PF_W8_FLUSH_U;                                    // passes in flight (8 survivors each)
-    const char *const img = reinterpret_cast<const char *>(p.xb8f);
     uint32_t rb = 0, cur = 0, meta = 0;                                 // next batch of records; what is left of this lane's record
     for (;;) {
         // ---- decode: one survivor per lane and round until the ring is empty or the list could not take another round
@@ -101,7 +99,7 @@ __device__ __forceinline__ void walk8_flush(const TileArgs &p, Walk8Lds &L, cons
                 id[u] = (uint32_t)(p.nb_first + (size_t)step0 * 32 + (ent & 0xFFFFFFu));
                 if (l < LU) {
                     va[u] = *reinterpret_cast<const u32x4 *>(p.xq8 + (q0 + (row[u] < q_valid ? row[u] : q_valid - 1)) * (size_t)D + 16 * l);
-                    vb[u] = *reinterpret_cast<const u32x4 *>(img + (((size_t)(id[u] >> 4) * NKS + (l >> 2)) * 1024 + (((l & 3u) << 4) + (id[u] & 15u)) * 16));
+                    vb[u] = *reinterpret_cast<const u32x4 *>(p.xb8 + (size_t)id[u] * (D + AUX8) + 16 * l);      // (the row-major image: a row is 2-3 cache lines there, 8 in fragment order)
                 } else {
                     va[u] = u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // lanes past the row: value 0 is stored as -128
                     vb[u] = va[u];
@@ -168,10 +166,12 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
     // ---- the query operand: lane l holds row l & 15 of each 16-row block, 16 consecutive k of every 64-deep step starting at 16 (l >> 4)
     i32x4w afrag[NI][NKS];
     auto load_afrag = [&]() {
+        const char *qimg = reinterpret_cast<const char *>(p.xq8);
+        asm volatile("" : "+s"(qimg));                                  // (opaque per call: otherwise the eight row addresses are kept in 16 registers through the walk for the rare reload)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const uint32_t r = 16u * i + ((uint32_t)lane & 15u);
-            const char *row = reinterpret_cast<const char *>(p.xq8) + (q0 + (r < q_valid ? r : q_valid - 1)) * (size_t)D;
+            const char *row = qimg + (q0 + (r < q_valid ? r : q_valid - 1)) * (size_t)D;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const uint32_t k = 64u * ks + 16u * ((uint32_t)lane >> 4);
@@ -224,7 +224,7 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) b[cb][ks] = *reinterpret_cast<const i32x4w *>(src + (cb * NKS + ks) * 1024);
         const int2 c = *reinterpret_cast<const int2 *>(c0img + (size_t)s * 32 + 2 * (lane & 15));
-        c0[0] = c.x; c0[1] = c.y;
+        c0[0] = -(c.x >> 1); c0[1] = -(c.y >> 1);                       // the image keeps C; the filter wants c0 = -floor(C / 2)
     };
     // two accumulator values of the sweep: the value passes where S + r0 + c0 >= 0; its sign bit is shifted into the lane's word (value 4 i + r ends
     // up in bit 31 - (4 i + r); set = fails)
@@ -233,10 +233,11 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         fail = __builtin_amdgcn_alignbit(fail, (uint32_t)(a[2 * r2 + 1] + c0), 31);
     };
     // the 8 x NKS matrix instructions of column block CB of a step beside the sweep of the other block's accumulators (column half c0s) into `fail`
-    auto half = [&](auto CBc, const i32x4w (&b)[2][NKS], int c0s, uint32_t &fail) {
+    auto half = [&](auto CBc, const i32x4w (&b)[2][NKS], int c0s, uint32_t &fail, auto &&pre) {
         constexpr int CB = decltype(CBc)::value;
         constexpr int NM = NI * NKS;                                    // matrix instructions of the half; 16 sweep pairs spread over them
         __builtin_amdgcn_sched_barrier(0);
+        pre();                                                          // (the next step's operand requests: placed between the matrix instructions, not in a burst)
         int g = 0;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -253,10 +254,12 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one matrix instruction ...
+            if (CB == 0 && m % 3 == 1 && m / 3 < 2 * NKS + 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // ... a request behind every third (the half that carries them) ...
             __builtin_amdgcn_sched_group_barrier(0x002, 64 / NM, 0);    // ... then its share of the sweep's 64 vector instructions
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto nothing = []() {};
     // verdict words -> records in the wave's ring: w0 belongs to block 0 of step s, w1 to block 1 of step s - 1 (finished one half later)
     auto append = [&](uint32_t f0, uint32_t f1, uint32_t s, bool first) {
         const uint32_t col0 = s * 32u + ((uint32_t)lane & 15u), col1 = col0 - 16u;       // (block 1 of step s - 1 = columns 32 (s - 1) + 16 ..)
@@ -264,10 +267,9 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         const uint32_t w1 = (!first && col1 < p.nb_count) ? ~f1 : 0u;
         const uint64_t m0 = __ballot(w0 != 0), m1 = __ballot(w1 != 0);
         if ((m0 | m1) == 0) return;                                     // wave-uniform
-        const uint64_t below = (1ull << lane) - 1;
         const uint32_t n0 = (uint32_t)__popcll(m0);
-        if (w0) L.ring[rc + (uint32_t)__popcll(m0 & below)] = make_uint2(w0, ((s - s0) << 7) | (uint32_t)lane);
-        if (w1) L.ring[rc + n0 + (uint32_t)__popcll(m1 & below)] = make_uint2(w1, ((s - 1 - s0) << 7) | 64u | (uint32_t)lane);
+        if (w0) L.ring[rc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = make_uint2(w0, ((s - s0) << 7) | (uint32_t)lane);
+        if (w1) L.ring[rc + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = make_uint2(w1, ((s - 1 - s0) << 7) | 64u | (uint32_t)lane);
         rc += n0 + (uint32_t)__popcll(m1);
     };
     auto flush_if_full = [&]() {
@@ -292,13 +294,12 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         const uint32_t ct = s0 + (s - s0) / 2;                         // (every second step is stamped: a period below = two steps)
 #endif
         PF_FSTAMP(0);
-        fetch(bB, c0B, s + 1 < s1 ? s + 1 : s1 - 1);
         PF_FSTAMP(1);
         f1 = 0;
-        half(std::integral_constant<int, 0>{}, bA, c0p, f1);
+        half(std::integral_constant<int, 0>{}, bA, c0p, f1, [&]() { fetch(bB, c0B, s + 1 < s1 ? s + 1 : s1 - 1); });
         PF_FSTAMP(2);
         uint32_t f0 = 0;
-        half(std::integral_constant<int, 1>{}, bA, c0A[0], f0);
+        half(std::integral_constant<int, 1>{}, bA, c0A[0], f0, nothing);
         PF_FSTAMP(3);
         append(f0, f1, s, s == s0);
         PF_FSTAMP(4);
@@ -306,11 +307,10 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         flush_if_full();
         PF_FSTAMP(5);
         if (s + 1 >= s1) break;                                         // wave-uniform
-        fetch(bA, c0A, s + 2 < s1 ? s + 2 : s1 - 1);
         f1 = 0;
-        half(std::integral_constant<int, 0>{}, bB, c0p, f1);
+        half(std::integral_constant<int, 0>{}, bB, c0p, f1, [&]() { fetch(bA, c0A, s + 2 < s1 ? s + 2 : s1 - 1); });
         f0 = 0;
-        half(std::integral_constant<int, 1>{}, bB, c0B[0], f0);
+        half(std::integral_constant<int, 1>{}, bB, c0B[0], f0, nothing);
         append(f0, f1, s + 1, false);
         c0p = c0B[1];
         flush_if_full();
