@@ -36,11 +36,9 @@ def _load():
             f"prefhetch_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C prefhetch_amd/csrc`. There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
-    lib.pf_status_str.restype = C.c_char_p
-    lib.pf_status_str.argtypes = [C.c_int32]
-    lib.pf_last_error.restype = C.c_char_p
-    lib.pf_last_error.argtypes = []
+    if not hasattr(lib, "pf_build_flags") and os.environ.get("PREFHETCH_HIP_LIB"):
+        # an older library named on purpose (A/B timing against an earlier round): it predates the build-flag record
+        return _bind(lib, skip=("pf_build_flags",))
     lib.pf_build_flags.restype = C.c_char_p
     lib.pf_build_flags.argtypes = []
     flags = (lib.pf_build_flags() or b"").decode()
@@ -48,6 +46,15 @@ def _load():
         # a timing-only ablation / debug build (pf_common.hpp) may only be loaded when it was asked for by path
         raise ImportError(f"prefhetch_amd: {LIB_PATH} is an experiment build ({flags}); it returns wrong results. "
                           "Rebuild with a plain `make -C prefhetch_amd/csrc`, or name it in PREFHETCH_HIP_LIB on purpose.")
+    return _bind(lib)
+
+
+def _bind(lib, skip=()):
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    lib.pf_status_str.restype = C.c_char_p
+    lib.pf_status_str.argtypes = [C.c_int32]
+    lib.pf_last_error.restype = C.c_char_p
+    lib.pf_last_error.argtypes = []
     lib.pf_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.pf_malloc.argtypes = [i32, C.POINTER(vp), sz]
     lib.pf_free.argtypes = [i32, vp]
@@ -106,6 +113,8 @@ def _load():
     lib.pf_ivfpq_get_list.argtypes = [vp, u32, vp, vp]
     lib.pf_ivfpq_search_lists.argtypes = [vp, vp, vp, sz, u32, vp, vp, sz, vp, vp]
     for name in SYMBOLS:
+        if name in skip:
+            continue
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         if name not in ("pf_status_str", "pf_last_error", "pf_build_flags"):
             fn.restype = C.c_int32

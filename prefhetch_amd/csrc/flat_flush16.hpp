@@ -68,6 +68,9 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 #ifndef PF_APPROX_UNROLL       // float4 pieces of a survivor's base row requested before the first is used (fp32 chain of the inexact path)
 #define PF_APPROX_UNROLL 8      // ... query rows staged in LDS (a walk's last flush)
 #endif
+#ifndef PF_APPROX_SLABS
+#define PF_APPROX_SLABS 0       // experiment: the last flush of an inexact walk staged slab by slab through LDS by LDS-DMA, 64 chains per wave -- 0.644 against 0.61 ms on N(0,1): the copies (16 line requests per survivor) cost what the per-lane loads did; off
+#endif
 #ifndef PF_APPROX_UNROLL2
 #define PF_APPROX_UNROLL2 4     // ... both rows from memory
 #endif
@@ -75,7 +78,8 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 // RING: the verdict words come from this wave's ring of records in LDS instead (the int8 walk appends a (word, tile, column block, lane) record per
 // non-zero word as the tile ends -- a ballot and an LDS write, no barrier -- and calls this only when a ring is nearly full or the walk ends:
 // the parking above cost a quarter of the int8 walk's time); rc records, ct_base = the walk's first tile.
-template <int D, int MT, int NJ, int TN, bool I8 = false, bool RING = false>
+// LAST: this instantiation is only ever the walk's last flush (compiled with the slab-wise evaluation of inexact survivors)
+template <int D, int MT, int NJ, int TN, bool I8 = false, bool RING = false, bool LAST = false>
 __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0, const uint2 *ring = nullptr, uint32_t rc = 0) {
@@ -226,6 +230,65 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
                 pd.rcnt[tid] = 0;
             }
+            if constexpr (PF_APPROX_SLABS && LAST && D % 64 == 0 && (((2u * BUF) / 4u) & ~15u) >= 16384u) {       // (two 8 KiB slab buffers per wave: rows of 128 and of 256 values)
+                // The walk's last flush (both tile buffers free).  One lane per survivor reading its own two rows from memory made the texture path
+                // see 64 different cache lines per load instruction: 82 us of a search on N(0,1) data (round 3's ablation).  Now every WAVE takes 64
+                // survivors at a time and walks their rows in slabs of 16 values: the slab's 64-byte pieces of the 64 query rows and the 64 base rows
+                // are copied by LDS-DMA (four row pieces per 16 lanes of a copy: whole cache lines) into the wave's own quarter of the buffers while
+                // the chains of the slab before run out of the other half of it -- all 64 lanes busy, no registers for staging, no workgroup barrier.
+                // LDS image of a slab: [x rows | y rows][64 rows][4 x 16 bytes], the four pieces of row r stored at position piece ^ ((r >> 2) & 3):
+                // 16 lanes reading their rows' same piece then hit 16 different 16-byte bank groups.
+                constexpr uint32_t QUARTER = ((2u * BUF) / 4u) & ~15u, SLABS = D / 16;
+                __syncthreads();                                          // the rows' ranges are reserved
+                const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+                char *const S0 = xstage + wv * QUARTER, *const S1 = S0 + 8192;
+                for (uint32_t eb = wv * 64u; eb < n; eb += 256u) {        // (per wave: the trip counts differ, no barrier inside)
+                    // the rows this lane copies: piece c of the image = rows 16 (c & 3) + (lane >> 2) of x (c < 4) or y, 16-byte part (lane & 3) of its slab
+                    uint32_t rix[8];                                      // (row numbers, not addresses: 8 registers through the slab loop instead of 16)
+#pragma unroll
+                    for (uint32_t c = 0; c < 8; ++c) {
+                        const uint32_t r = 16u * (c & 3u) + (lane >> 2);
+                        uint32_t e = eb + r;
+                        e = e < n ? e : n - 1;
+                        rix[c] = c < 4 ? (uint32_t)q0 + pd.loc[e] : pd.id[e];
+                    }
+                    const uint32_t part = 4u * ((lane & 3u) ^ ((lane >> 4) & 3u));     // this lane's 16-byte part of a slab: (lane & 3) ^ ((r >> 2) & 3), r = 16 (c & 3) + (lane >> 2)
+                    const uint32_t e = eb + lane < n ? eb + lane : n - 1, row = pd.loc[e], id = pd.id[e];
+                    const float bnv = p.bn[id];
+                    auto copy_slab = [&](uint32_t sl, char *buf) {
+#pragma unroll
+                        for (uint32_t c = 0; c < 8; ++c) {
+                            const float *srcp = (c < 4 ? p.xq : p.xb) + (size_t)rix[c] * D + part + 16u * sl;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcp,
+                                                             (__attribute__((address_space(3))) void *)(buf + 1024u * c), 16, 0, 0);
+                        }
+                    };
+                    copy_slab(0, S0);
+                    float acc = 0.f;
+                    for (uint32_t sl = 0; sl < SLABS; ++sl) {
+                        const bool odd = (sl & 1u) != 0;
+                        char *const cur = odd ? S1 : S0, *const nxt = odd ? S0 : S1;   // (selects on one condition: the alias analysis sees that the copy in flight never touches the slab being read)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this slab has landed (wave-private: nobody else to wait for)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (sl + 1 < SLABS) copy_slab(sl + 1, nxt);
+                        const char *xr = cur + lane * 64u, *yr = cur + 4096u + lane * 64u;
+#pragma unroll
+                        for (uint32_t t = 0; t < 4; ++t) {
+                            const uint32_t pos = (t ^ ((lane >> 2) & 3u)) * 16u;
+                            const float4 a = *reinterpret_cast<const float4 *>(xr + pos), b = *reinterpret_cast<const float4 *>(yr + pos);
+                            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                    if (eb + lane < n) {
+                        const uint32_t pos = atomicAdd(&pd.rbase[row], 1u);
+                        if (pos < p.cap) {                                // (at or past cap: the list of this query overflowed, k_select rescans the chunk)
+                            const float dist = fmaf(-2.f, acc, sA[2 * row] + bnv);
+                            p.cand[(q0 + row) * p.cap + pos] = make_key(dist < 0.f ? 0.f : dist, id);
+                        }
+                    }
+                }
+            } else
             for (uint32_t r0 = 0; r0 < (xstage ? 128u : 1u); r0 += XROWS) {           // (without staging: one round over everything)
                 if (xstage) {
                     if (r0) __syncthreads();                              // the first half's readers are done

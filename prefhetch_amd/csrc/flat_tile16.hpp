@@ -376,7 +376,8 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
                 rc = 0;
             }
         } else if constexpr (FILTER) {
-            if (u == MT - 1 || ct + 1 == ct1) {                         // workgroup-uniform
+            // (the walk's LAST flush is issued behind the loop, where the query fragments and thresholds are dead: it may use their registers)
+            if (u == MT - 1 && ct + 1 != ct1) {                         // workgroup-uniform
                 uint32_t surv[MT][NJ];
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
@@ -387,10 +388,24 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #else
                 constexpr bool abl_exact = false;
 #endif
-                pend16_flush<D, MT, NJ, TN, I8>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, ct + 1 == ct1 ? smem : buf_cur, q_valid, ct + 1 == ct1, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ, TN, I8, false, false>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, buf_cur, q_valid, false, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
+        }
+    }
+    if constexpr (FILTER && !I8) {
+        if (ct1 > ct0) {                                                // workgroup-uniform: the walk's last flush (both tile buffers are free: nothing in flight, nobody reads them)
+            const uint32_t u_last = (ct1 - 1 - ct0) % MT;
+            uint32_t surv[MT][NJ];
+#pragma unroll
+            for (int e = 0; e < MT * NJ; ++e) surv[e / NJ][e % NJ] = sv[e];
+#ifdef PF_ABL_EXACTFLUSH
+            constexpr bool abl_exact2 = true;
+#else
+            constexpr bool abl_exact2 = false;
+#endif
+            pend16_flush<D, MT, NJ, TN, I8, false, true>(p, pend, stage, q0, tid, surv, ct1 - 1 - u_last, wm, wn, approx && !abl_exact2, smem, q_valid, true, (ct1 - 1 - ct0) / MT);
         }
     }
 }
@@ -400,12 +415,15 @@ constexpr size_t TILE8_LDS = 4 * 17024;
 template <int D, size_t SMEM_BYTES>
 __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t group, char *smem, float *stage, Pend16 &pend, const uint32_t qt, const uint32_t grp);
 
-template <bool FILTER, int D>
+// WITH8: the instantiation that carries the streamed int8 walk (8-bit bases).  Bases that are not 8-bit launch the one without it: the walk's mere
+// presence in the kernel changes the code hipcc builds for the bf16 loop (an s_waitcnt vmcnt(0) behind the tile's first copy request: +8 % on the
+// long chunk of an N(0,1) search).
+template <bool FILTER, int D, bool WITH8 = false>
 __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = typename Geo16Of<D>::type;
     constexpr int TM = GEO::TM, TN = GEO::TN, PITCH = (D + (int)AUX16) * 2;
     constexpr size_t SMEM_T = 2 * (size_t)TN * PITCH > F32_TILE_LDS<GEO> ? 2 * (size_t)TN * PITCH : F32_TILE_LDS<GEO>;   // the fp32 fallback borrows this LDS
-    constexpr size_t SMEM = (FILTER && D % 32 == 0 && D <= 128 && SMEM_T < TILE8_LDS) ? TILE8_LDS : SMEM_T;             // ... and so do the four waves of the streamed int8 walk
+    constexpr size_t SMEM = (WITH8 && SMEM_T < TILE8_LDS) ? TILE8_LDS : SMEM_T;                                         // ... and so do the four waves of the streamed int8 walk
     __shared__ __align__(16) char smem[SMEM];
     __shared__ __align__(16) float stage[4 * TM];                   // the epilogue's per-row (norm, threshold) pairs and counters
     __shared__ Pend16 pend;                                         // survivors parked until the end of the walk (FILTER)
@@ -417,7 +435,7 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
     // lists overflowed, fp32 tiles from then on): the int8 matrix instruction.  Anything else: bf16 operands.
     if constexpr (D % 32 == 0 && D <= 128) {
         if (p.xb8 && !(qflags & 7u)) {
-            if constexpr (FILTER && PF_B16_TN == 128) {
+            if constexpr (WITH8) {
                 if (!p.i8_old) { tile8_walk<D, SMEM>(p, group, smem, stage, pend, qt, grp); return; }
             }
             tile16_walk<FILTER, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);

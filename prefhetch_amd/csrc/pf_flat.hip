@@ -372,7 +372,9 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
             switch (f->d) {
-#define PF_T16(DD) case DD: if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \
+#define PF_T16(DD) case DD: if (filter && DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128 && b8 && !t.i8_old) \
+                                hipLaunchKernelGGL((k_l2_tile16<true, DD, (DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128)>), grid16, dim3(256), 0, s, t, g32, n32); \
+                            else if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \
                             else hipLaunchKernelGGL((k_l2_tile16<false, DD>), grid16, dim3(256), 0, s, t, g32, n32); break;
 #ifdef PF_DEV_ONLY_D128   // development builds (compile time, ISA inspection): rows of 128 values only -- other row lengths are NOT searched (experiment switch)
                 PF_T16(128)
