@@ -416,6 +416,124 @@ PF_HD void body_ksB(const A &ar, const TwU64 *__restrict__ tw, const TwU64 *__re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same split for the stand-alone transforms and the fused ciphertext x plaintext at N = 32768 (round 4): the single-kernel
+// transform hands a CU to one workgroup at this degree and its phases serialise (26 % / 24 % / 18 % of 8 TB/s for forward /
+// inverse / ct x pt at config 5).  Here a limb-polynomial goes through small workgroups, IN PLACE in the output buffer:
+//   forward   pass A (body_ksA: stages 0..6 on 128 x 64 tiles)  ->  body_nsB<NS_FWD>  (stages 7..14 per 256-point block, canonical form)
+//   inverse   body_nsB<NS_INV> (stages 14..7 per block)  ->  body_nsC (stages 6..0 on tiles, N^-1 folded in, canonical form)
+//   ct x pt   pass A  ->  body_nsB<NS_MUL> (stages 7..14, product with the NTT-form plaintext, stages 14..7)  ->  body_nsC
+// Every pass reads and writes the same index set per workgroup (a tile, or a block), so no workspace is needed; the host runs the
+// passes over rounds of polynomials small enough for the intermediate to stay in the 256 MB Infinity Cache (pf_ntt.hip).
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef PF_NS_MODES
+#define PF_NS_MODES
+enum { NS_FWD = 0, NS_INV = 1, NS_MUL = 2 };
+#endif
+
+// in     the limb-polynomial to read (natural index order): pass A's output for NS_FWD / NS_MUL (= data), NTT form for NS_INV
+// data   where the block is written back (the same 256 indices it was read from: in may equal data)
+// pt     NS_MUL: this limb's plaintext in NTT form
+// chunk  which 2048 coefficients (0..15) this workgroup covers
+template <class A, int MODE, class WSync>
+PF_HD void body_nsB(const A &ar, const TwU64 *__restrict__ tw, const TwU64 *__restrict__ itw, const uint64_t *in, uint64_t *data, const uint64_t *__restrict__ pt,
+                    int chunk, uint64_t *lds, int tid, WSync &&wsync) {
+    static_assert(std::is_same<typename A::V, uint64_t>::value, "the split transforms run the 64-bit lazy family");
+    const int lane = tid & 63, wv = tid >> 6, h = lane >> 5, l = lane & 31;
+    const int blk = chunk * 8 + wv * 2 + h;
+    uint64_t *area = lds + wv * KsGeo::B_LDS_WAVE + h * 320;
+    const size_t base = (size_t)blk * 256;
+    uint64_t r[8];
+    KsbTw T;
+    if constexpr (MODE != NS_INV) {
+        T.load(tw, blk, l);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                              // R1 order: 16 bytes per lane, 512 contiguous bytes per half-wave
+            const U64x2 v = *reinterpret_cast<const U64x2 *>(in + base + 128 * (kk >> 1) + 64 * (kk & 1) + 2 * l);
+            r[2 * kk] = v.x; r[2 * kk + 1] = v.y;
+        }
+        U64x2 kv[4];
+        ksb_finish_fwd(r, ar, T, l, area, wsync, [&] {
+            if constexpr (MODE == NS_MUL) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kv[j] = *reinterpret_cast<const U64x2 *>(pt + base + 8 * l + 2 * j);
+                PF_SCHED_FENCE();
+            }
+        });
+        if constexpr (MODE == NS_FWD) {
+            // canonical form; stores staged through the half-wave's area so that every store instruction covers 512 contiguous bytes
+            ks_reduce_all<8>(r, ar);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = ar.canon_small(r[e]);
+            U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[j] = U64x2{r[2 * j], r[2 * j + 1]};
+            wsync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = 2 * (32 * j + l);                      // coefficient pair number 32 j + l
+                *reinterpret_cast<U64x2 *>(data + base + cc) = *reinterpret_cast<const U64x2 *>(area + ksb_p2(cc));
+            }
+            wsync();
+            return;
+        } else {
+            // dyadic product with the plaintext on this lane's 8 consecutive NTT-form coefficients: x < 2^62, pt < q < 2^56
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint64_t l4[4] = {0, 0, 0, 0}, h4[4] = {0, 0, 0, 0};
+                const uint64_t x4[4] = {r[4 * g], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3]};
+                const uint64_t k4[4] = {kv[2 * g].x, kv[2 * g].y, kv[2 * g + 1].x, kv[2 * g + 1].y};
+                ks_mac128x4(l4, h4, x4, k4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[4 * g + e] = ar.barrett128(l4[e], h4[e]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                 // R3 order: a lane owns 8 consecutive NTT-form coefficients
+            const U64x2 v = *reinterpret_cast<const U64x2 *>(in + base + 8 * l + 2 * j);
+            r[2 * j] = v.x; r[2 * j + 1] = v.y;
+        }
+    }
+    // the first eight inverse stages, as in body_ksB<INV>: R3 (14, 13, 12), R2 (11, 10, 9), R1 (8, 7); the block leaves in R1 order, in [0, 2q)
+    T.load(itw, blk, l);
+    const int hi2 = l >> 3;
+    ks_inv_stage<8, 0, 0, false>(r, ar, [&](int g) { return T.s14[g]; });
+    ks_inv_stage<8, 1, 1, false>(r, ar, [&](int g) { return T.s13[g]; });
+    ks_inv_stage<8, 2, 2, false>(r, ar, [&](int) { return T.s12; });
+    {
+        U64x2 *wr = reinterpret_cast<U64x2 *>(area + 10 * l);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[j] = U64x2{r[2 * j], r[2 * j + 1]};
+        wsync();
+        const uint64_t *rd = area + ksb_p2(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = rd[10 * k];
+    }
+    ks_inv_stage<8, 0, 3, false>(r, ar, [&](int g) { return T.s11[g]; });
+    ks_inv_stage<8, 1, 4, false>(r, ar, [&](int g) { return T.s10[g]; });
+    ks_inv_stage<8, 2, 5, false>(r, ar, [&](int) { return T.s9; });
+    ks_reduce_all<8>(r, ar);
+    wsync();
+    {
+        uint64_t *wr = area + ksb_p1(64 * hi2) + 2 * (l & 3) + ((l >> 2) & 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[8 * k] = r[k];
+        wsync();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const U64x2 v = *reinterpret_cast<const U64x2 *>(area + ksb_p1(128 * (kk >> 1) + 64 * (kk & 1)) + 2 * l);
+            r[2 * kk] = v.x; r[2 * kk + 1] = v.y;
+        }
+    }
+    ks_inv_stage<8, 1, 0, false>(r, ar, [&](int g) { return T.s8[g]; });
+    ks_inv_stage<8, 2, 1, false>(r, ar, [&](int) { return T.s7; });
+    ks_reduce_all<8>(r, ar);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<U64x2 *>(data + base + 128 * (kk >> 1) + 64 * (kk & 1) + 2 * l) = U64x2{r[2 * kk], r[2 * kk + 1]};
+    wsync();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Pass C: inverse stages 6..0 (index bits 8..14) of the sums that pass B left half-way, then SEAL's division by the special
 // prime P with rounding, added into the ciphertext -- steps 3 and 4 of switch_key_inplace in one pass over the sums.
 // A workgroup of 512 threads owns the tile of columns [64 cb, 64 cb + 64) of ONE (ciphertext, component) and walks limbs:
@@ -513,6 +631,17 @@ PF_HD void body_ksC(LimbFn &&limb, const uint64_t *__restrict__ acc, uint64_t *_
             c0[(size_t)k * 2048] = x >= q ? x - q : x;
         }
     }
+}
+
+// Inverse stages 6..0 of one tile of a half-inverted limb-polynomial, in place: canonical coefficients out (natural order).
+template <class A, class Sync>
+PF_HD void body_nsC(const A &ar, const TwU64 *__restrict__ itw, uint64_t *data, int cb, uint64_t *lds, int tid, Sync &&sync) {
+    const int lane = tid & 63, w = wave_uniform(tid >> 6);
+    uint64_t r[16];
+    ksc_inverse_tile(r, ar, itw, data, cb, lds, tid, sync);
+    uint64_t *c0 = data + (size_t)w * 256 + cb * 64 + lane;            // registers = r div 8, wave = r mod 8
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c0[(size_t)k * 2048] = r[k];
 }
 
 }  // namespace pf

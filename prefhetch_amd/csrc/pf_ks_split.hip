@@ -68,6 +68,50 @@ __global__ void __launch_bounds__(KsGeo::A_T, PF_KSC_WAVES) k_ksC(KsSplitArgs p,
     body_ksC<AL>(limb, p.acc + b * 2 * p.K * N, p.ct + b * 2 * p.D * N, comp, (int)p.D, (int)p.K, (int)j0, (int)j1, (int)cb, lds, (int)threadIdx.x, WgSync{});
 }
 
+// ---- the split stand-alone transforms / ct x pt (ks_split.hpp: body_nsB, body_nsC) ------------------------------------------------
+// Block id = polynomial * 4 + column tile (passes A and C) or polynomial * 16 + chunk (pass B): the pieces of a polynomial are
+// neighbours in the grid.
+__global__ void __launch_bounds__(KsGeo::A_T, 4) k_nsA(NsArgs p) {
+    __shared__ uint64_t lds[KsGeo::A_LDS];
+    const uint32_t cb = blockIdx.x & 3;
+    const size_t poly = blockIdx.x >> 2;
+    const LimbDev &lm = p.limbs[poly % p.L];
+    const AL ar = ArithOf<AL>::make(lm);
+    body_ksA<AL>(ar, ArithOf<AL>::fwd(p.tables, lm), p.src + poly * KsGeo::N, p.data + poly * KsGeo::N, (int)cb, lds, (int)threadIdx.x, WgSync{});
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(KsGeo::B_T, 2) k_nsB(NsArgs p) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[KsGeo::B_LDS];
+    const uint32_t chunk = blockIdx.x & 15;
+    const size_t poly = blockIdx.x >> 4;
+    const uint32_t limb = (uint32_t)(poly % p.L);
+    const LimbDev &lm = p.limbs[limb];
+    const AL ar = ArithOf<AL>::make(lm);
+    const uint64_t *pt = nullptr;
+    if constexpr (MODE == NS_MUL) pt = p.pt + ((p.pt_broadcast ? 0 : poly / (2 * (size_t)p.L)) * p.L + limb) * KsGeo::N;
+    body_nsB<AL, MODE>(ar, ArithOf<AL>::fwd(p.tables, lm), ArithOf<AL>::inv(p.tables, lm), (MODE == NS_INV ? p.src : p.data) + poly * KsGeo::N, p.data + poly * KsGeo::N, pt,
+                       (int)chunk, lds, (int)threadIdx.x, WaveSync{});
+}
+
+__global__ void __launch_bounds__(KsGeo::A_T, 4) k_nsC(NsArgs p) {
+    __shared__ uint64_t lds[KsGeo::A_LDS];
+    const uint32_t cb = blockIdx.x & 3;
+    const size_t poly = blockIdx.x >> 2;
+    const LimbDev &lm = p.limbs[poly % p.L];
+    const AL ar = ArithOf<AL>::make(lm);
+    body_nsC<AL>(ar, ArithOf<AL>::inv(p.tables, lm), p.data + poly * KsGeo::N, (int)cb, lds, (int)threadIdx.x, WgSync{});
+}
+
+void launch_nsA(const NsArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_nsA, dim3((unsigned)(a.n * KsGeo::A_TILES)), dim3(KsGeo::A_T), 0, s, a); }
+void launch_nsB(const NsArgs &a, int mode, hipStream_t s) {
+    const dim3 grid((unsigned)(a.n * KsGeo::B_CHUNKS)), block(KsGeo::B_T);
+    if (mode == NS_FWD) hipLaunchKernelGGL(k_nsB<NS_FWD>, grid, block, 0, s, a);
+    else if (mode == NS_INV) hipLaunchKernelGGL(k_nsB<NS_INV>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_nsB<NS_MUL>, grid, block, 0, s, a);
+}
+void launch_nsC(const NsArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_nsC, dim3((unsigned)(a.n * KsGeo::A_TILES)), dim3(KsGeo::A_T), 0, s, a); }
+
 void launch_ksA(const KsSplitArgs &a, hipStream_t s) {
     const size_t grid = (size_t)a.nb * a.D * a.nJ * KsGeo::A_TILES;
     hipLaunchKernelGGL(k_ksA, dim3((unsigned)grid), dim3(KsGeo::A_T), 0, s, a);

@@ -38,6 +38,13 @@ struct pf_ctx {
     int ks_split = 1;               // N = 32768, lazy 64-bit family: the two-pass digit transforms of ks_split.hpp (PF_KS_SPLIT: 0 off,
                                     // 1 with the inverse transforms and the division by P fused into passes B and C, 2 with k_ntt + k_ks_moddown)
     bool split_ok() const { return logn == 15 && arith() == 2 && ks_split; }
+    // the same split for the stand-alone transforms and the fused ct x pt (ks_split.hpp: body_nsB / body_nsC).  PF_NS_SPLIT: bit 0 forward,
+    // bit 1 inverse, bit 2 ct x pt; PF_NS_ROUND: limb-polynomials per round.  Measured at config 5 (profiles/r04_ns_*): every pass moves the
+    // whole batch through memory again at 4.2-5 TB/s with the vector pipe ~50 % busy -- forward 1.70 -> 1.57 ms (rounds of 960), inverse
+    // 1.88 -> 1.81, ct x pt 3.52 -> 3.82 ms: only the forward transform takes the split by default.
+    int ns_split = 1;
+    size_t ns_round = 960;
+    bool ns_ok(int op) const { return logn == 15 && arith() == 2 && ((ns_split >> op) & 1); }
     size_t round_size(size_t B) const {
         const uint32_t K = L, D = K - 1;
         // ciphertexts per round: a multiple of 16 with at most ~4096 digit transforms per launch up to N = 16384 (192 at N = 8192 with
@@ -204,6 +211,8 @@ pf_status pf_ctx_create(pf_ctx **out, int device, uint32_t N, uint32_t L, const 
     if (const char *e = getenv("PF_KS_ROUND")) { const long v = atol(e); if (v > 0) c->ks_round = (size_t)v; }
     if (const char *e = getenv("PF_KS_JROUND")) { const long v = atol(e); if (v > 0) c->ks_jround = (uint32_t)v; }
     if (const char *e = getenv("PF_KS_SPLIT")) c->ks_split = atoi(e);
+    if (const char *e = getenv("PF_NS_SPLIT")) c->ns_split = atoi(e);
+    if (const char *e = getenv("PF_NS_ROUND")) { const long v = atol(e); if (v > 0) c->ns_round = (size_t)v; }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
@@ -279,14 +288,37 @@ pf_status pf_ctx_force_u64(pf_ctx *c, int on) {
     return PF_OK;
 }
 
+namespace {
+// N = 32768, lazy 64-bit family: the transforms as passes of small workgroups over rounds of polynomials (ks_split.hpp), in place in dst.
+// op: 0 forward, 1 inverse, 2 ct x pt (pt non-null).  A round is a multiple of 2 L polynomials so that limbs and ciphertexts stay aligned.
+pf_status run_ns_split(pf_ctx *c, int op, const uint64_t *src, uint64_t *dst, const uint64_t *pt, bool pt_broadcast, size_t n, pf_stream stream) {
+    if (n == 0) return PF_OK;
+    PF_GUARD(c->device);
+    hipStream_t s = as_stream(stream);
+    const size_t unit = 2 * (size_t)c->L;
+    size_t round = c->ns_round / unit * unit;
+    if (round < unit) round = unit;
+    for (size_t off = 0; off < n; off += round) {
+        const size_t cnt = n - off < round ? n - off : round;
+        NsArgs a{c->d_limbs, c->d_tables, src + off * c->N, dst + off * c->N, pt ? pt + (pt_broadcast ? 0 : off / unit * c->L * c->N) : nullptr, c->L, pt_broadcast ? 1u : 0u, cnt};
+        if (op == 1) { launch_nsB(a, NS_INV, s); launch_nsC(a, s); }
+        else { launch_nsA(a, s); launch_nsB(a, op == 0 ? NS_FWD : NS_MUL, s); if (op == 2) launch_nsC(a, s); }
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+}  // namespace
+
 pf_status pf_ntt_forward_to(pf_ctx *c, const uint64_t *src, uint64_t *dst, size_t n, pf_stream stream) {
     if (!c || ((!src || !dst) && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (c->ns_ok(0) && n % c->L == 0) return run_ns_split(c, 0, src, dst, nullptr, false, n, stream);
     NttArgs a{c->d_limbs, c->d_tables, src, dst, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }
 
 pf_status pf_ntt_inverse_to(pf_ctx *c, const uint64_t *src, uint64_t *dst, size_t n, pf_stream stream) {
     if (!c || ((!src || !dst) && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
+    if (c->ns_ok(1) && n % c->L == 0) return run_ns_split(c, 1, src, dst, nullptr, false, n, stream);
     NttArgs a{c->d_limbs, c->d_tables, src, dst, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 1, 0, a, n, stream);
 }
@@ -305,6 +337,7 @@ pf_status pf_ct_pt_mul(pf_ctx *c, const uint64_t *ct, const uint64_t *pt_ntt, si
     if (!ct || !pt_ntt || !out) return fail(PF_ERR_INVALID_ARG, "null argument");
     if (pt_count != 1 && pt_count != B) return fail(PF_ERR_INVALID_ARG, "pt_count must be 1 (broadcast) or B");
     if (flags & ~7) return fail(PF_ERR_INVALID_ARG, "unknown flag bits");
+    if (c->ns_ok(2) && flags == 0) return run_ns_split(c, 2, ct, out, pt_ntt, pt_count == 1, B * 2 * (size_t)c->L, stream);
     const size_t pairs = B * (size_t)c->L;
     NttArgs a{c->d_limbs, c->d_tables, ct, out, pt_ntt, pairs, c->L, pt_count == 1 ? 1u : 0u, 0};
     return run_ntt_like(c, 2, flags, a, (pairs + 7) / 8 * 16, stream);     // grid: 8 XCD streams x 2 polynomials per pair

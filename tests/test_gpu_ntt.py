@@ -205,6 +205,36 @@ def test_config5_ring_ct_pt_slice(pf):
     assert (pf.to_host_u64(d) == ct).all()
 
 
+@pytest.mark.parametrize("mask,L,B", [(7, 15, 3), (7, 2, 5), (0, 15, 2), (5, 4, 40)])
+def test_config5_split_passes(pf, monkeypatch, mask, L, B):
+    """N = 32768, lazy 64-bit family: the transforms and the fused ct x pt as passes of small workgroups (ks_split.hpp: pass A,
+    body_nsB, body_nsC), every mode switched on (PF_NS_SPLIT is read when the context is created), a round shorter than the batch,
+    in place and out of place, edge values -- against the oracle, bit for bit; mask 0 = the single-kernel path on the same data."""
+    monkeypatch.setenv("PF_NS_SPLIT", str(mask))
+    monkeypatch.setenv("PF_NS_ROUND", str(4 * L))                     # two ciphertexts per round: several rounds, the last one short
+    N, qs = 32768, oracle.BFV_DEFAULT[32768][:L]
+    rng = np.random.default_rng(32768 + 17 * mask + L)
+    o = oracle.Oracle(N, qs)
+    c = pf.RnsContext(N, qs, _dev())                                  # (not the cached context: the knobs are per context)
+    ct = np.stack([rng.integers(0, q, (B, 2, N), dtype=np.uint64) for q in qs], axis=2)
+    ct[0, 0, :, :4] = np.array(qs, dtype=np.uint64)[:, None] - 1      # q - 1 and 0 in the first slots
+    ct[0, 1, :, :4] = 0
+    pt = np.stack([rng.integers(0, q, (B, N), dtype=np.uint64) for q in qs], axis=1)
+    d_ct, d_pt = pf.to_device_u64(ct, _dev()), pf.to_device_u64(pt, _dev())
+    exp = o.ct_pt_mul(ct, pt)
+    assert (pf.to_host_u64(c.ct_pt_mul(d_ct, d_pt)) == exp).all()                        # out of place
+    assert (pf.to_host_u64(d_ct) == ct).all()                                            # ... and the input untouched
+    assert (pf.to_host_u64(c.ct_pt_mul(d_ct, d_pt[:1])) == o.ct_pt_mul(ct, pt[:1])).all()   # broadcast plaintext
+    d = d_ct.clone()
+    assert (pf.to_host_u64(c.ct_pt_mul(d, d_pt, out=d)) == exp).all()                    # in place
+    f = o.ntt_forward(ct)
+    d = d_ct.clone()
+    c.ntt_forward_(d)
+    assert (pf.to_host_u64(d) == f).all()
+    c.ntt_inverse_(d)
+    assert (pf.to_host_u64(d) == ct).all()
+
+
 KS_CONFIGS = [  # (N, key moduli: data primes + special prime last, batch)
     (1024, [0x7FFFFFFFE90001, 0x7FFFFFFFBF0001, 0xFFFFFFFFF70001], 3),
     (4096, oracle.BFV_DEFAULT[4096], 5),                        # 36/36-bit data + 37-bit special: exact-FP64 NTTs
