@@ -264,7 +264,12 @@ def config5_block(pf, dev):
     ok_ctpt = bool((pf.to_host_u64(out[rows]) == o.ct_pt_mul(h_ct, h_pt)).all())
     ms_fwd = _timed(lambda: ctx.ntt_forward(ct, out=out), 5)
     ok_fwd = bool((pf.to_host_u64(out[rows]) == o.ntt_forward(h_ct)).all())
-    ms_inv = _timed(lambda: ctx.ntt_inverse(out, out=out), 5)
+    ms_inv = _timed(lambda: ctx.ntt_inverse(out, out=out), 5)          # (timed in place on its own output: only the duration is used)
+    # the inverse transform against the oracle as well: the inverse of the forward transform of the rows must be the rows
+    chk = ctx.ntt_forward(ct[rows].contiguous())
+    ctx.ntt_inverse(chk, out=chk)
+    ok_inv = bool((pf.to_host_u64(chk) == h_ct).all()) and bool((pf.to_host_u64(ctx.ntt_inverse(ctx.ntt_forward(ct[rows].contiguous()))) == o.ntt_inverse(o.ntt_forward(h_ct))).all())
+    del chk
     n_polys = B * 2 * D
     del pt, out
     # key switching: the context holds the key moduli (special prime last); one polynomial per ciphertext is switched
@@ -287,9 +292,12 @@ def config5_block(pf, dev):
             "key_switch_ms_per_256": ms_ks, "key_switch_us_per_polynomial": 1e3 * ms_ks / B,
             "key_switch_digit_transforms": B * D * K, "key_switch_ns_per_digit_transform": 1e6 * ms_ks / (B * D * K),
             "key_switch_algorithmic_bytes": ks_bytes, "key_switch_frac_of_hbm_peak": ks_bytes / (ms_ks * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "key_switch_bound": "valu (61 440 transforms of 32768 points in 64-bit modular arithmetic per batch; PMC: profiles/r03_pmc_keyswitch.txt)",
+            "key_switch_bound": "valu (61 440 transforms of 32768 points in 64-bit modular arithmetic per batch; PMC: profiles/r03_z_pmc_keyswitch.txt)",
+            # what the counters saw (2 x FETCH_SIZE + WRITE_SIZE of k_ksA / k_ksB / k_ksC, profiles/r03_z_pmc_keyswitch.txt: 5.67 GB per round of
+            # 32 ciphertexts): the intermediate digit transforms cross memory once each way -- not collected in this run
+            "key_switch_counter_bytes_per_256": 45.4e9, "key_switch_counter_over_algorithmic": 45.4e9 / ks_bytes,
             "verified_rows_vs_oracle": rows,
-            "verified": {"ct_x_pt": ok_ctpt, "forward_ntt": ok_fwd, "key_switch": ok_ks}}
+            "verified": {"ct_x_pt": ok_ctpt, "forward_ntt": ok_fwd, "inverse_ntt": ok_inv, "key_switch": ok_ks}}
 
 
 def main():
@@ -640,7 +648,7 @@ def main():
             "roofline_prefilter": (
                 {"kernel": "k_l2_tile16 (int8 walk; + k_select, k_rows_prep), whole stage", "bound": "mfma", "achieved": tf, "peak": I8_MATRIX_PEAK_TOPS,
                  "unit": "TOP/s", "frac": tf / I8_MATRIX_PEAK_TOPS, "flops_per_step": flops, "stage_ms": ms_a, "dominant_by_time": ms_a > ms_b,
-                 "operands": "int8 (value - 128) with int32 accumulation, v_mfma_i32_32x32x32_i8: every value of base and queries is an integer in [0, 255] (checked on the "
+                 "operands": "int8 (value - 128) with int32 accumulation, v_mfma_i32_16x16x64_i8 (filtered launches; streamed from a fragment-order image) / 32x32x32 (bootstrap): every value of base and queries is an integer in [0, 255] (checked on the "
                              "device, value by value; anything else runs the bf16 tiles), thresholds are integers in the accumulators' initial values, survivors "
                              "are evaluated exactly (v_dot4_u32_u8): (D, I) equal the fp32-operand path's and the bf16 tiles' bit for bit "
                              "(prefilter_variants.fp32_operands_bit_identical_to_timed_path, .bf16_operands_bit_identical_to_timed_path)",

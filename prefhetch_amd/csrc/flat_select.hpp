@@ -202,6 +202,77 @@ __device__ __forceinline__ bool radix_bootstrap(uint64_t *keys, uint32_t &cnt, u
     return true;
 }
 
+// Bootstrap by sampling (batches, exact operands): four radix passes over all 8192 distances of a row made the first selection of a search 27 us
+// for 1024 queries.  Here the row's first THREADS distances are a sample; the sample value of rank r (ranks by counting: every thread compares its
+// sample with all of them, broadcast LDS reads) is a threshold that lets about 2.5 k of the n distances through; those few hundred keys are collected
+// and the caller cuts them to the k smallest (radix_cut over the survivors only).  Returns false -- nothing collected -- when the threshold let
+// fewer than k or more than the reservoir holds through (then the radix selection above runs): the result never depends on the sample.
+constexpr uint32_t BOOT_CUT_VPT = 16;                           // keys per lane of the wave that cuts a sampled bootstrap down to k (1024 keys: 32 registers)
+template <uint32_t THREADS>
+__device__ __forceinline__ bool sample_bootstrap(uint64_t *keys, uint32_t &cnt, uint32_t *hist, uint32_t *ctl, uint32_t k, const float *row, size_t nb_first,
+                                                 uint32_t n, int tid) {
+    static_assert(THREADS == 256, "the sample lives in the 256-word histogram");
+    constexpr int VPT = 8192 / THREADS;
+    if (n < 8 * THREADS || 3 * (uint64_t)k * THREADS > (uint64_t)n * (THREADS - 2)) return false;       // workgroup-uniform: too few rows to sample, or k too large a share of them
+    uint32_t u[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t col = tid + e * THREADS;
+        u[e] = col < n ? __float_as_uint(row[col]) : 0xFFFFFFFFu;    // the filler is above every distance
+    }
+#if defined(PF_ABL_SEL_STAGE) && PF_ABL_SEL_STAGE == 1   // ablation (timing only, wrong results): the row is loaded, nothing is selected
+    { uint32_t x = 0;
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) x ^= u[e];
+      if (x == 0x5EEDFACEu) ctl[5] = x; }
+    return true;
+#endif
+    hist[tid] = u[0];
+    __syncthreads();
+    // The sample value that lets about 2.5 k of the n distances through: the one with `want` samples below it (want >= 2.5 k THREADS / n).  ONE
+    // wave finds it: every lane sorts four samples, then the wave pops its smallest head `want` + 1 times (a DPP minimum and a ballot per pop) --
+    // ranking every sample against all the others by broadcast LDS reads kept the CU's LDS pipe busy for 10 us (five workgroups per CU).
+    const uint32_t want = (uint32_t)((5ull * k * THREADS + 2ull * n - 1) / (2ull * n)) + 1u;
+    if ((uint64_t)want * n > (uint64_t)(64 * BOOT_CUT_VPT * 3 / 4) * THREADS) return false;           // workgroup-uniform: more than the cutting wave holds (large k): the radix selection
+    if (tid < 64) {
+        const u32x4 sv = *reinterpret_cast<const u32x4 *>(&hist[4 * tid]);
+        uint32_t a = sv[0], b = sv[1], c = sv[2], d = sv[3];
+        auto cx = [](uint32_t &x, uint32_t &y) { const uint32_t lo = x < y ? x : y, hi = x < y ? y : x; x = lo; y = hi; };
+        cx(a, b); cx(c, d); cx(a, c); cx(b, d); cx(b, c);             // a <= b <= c <= d
+        uint32_t below = 0, thr_v = 0;
+        for (;;) {                                                    // wave-uniform trip count
+            uint32_t m = a;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = __shfl_xor(m, sh); m = o < m ? o : m; }
+            const uint64_t eq = __ballot(a == m);
+            thr_v = m;
+            below += (uint32_t)__popcll(eq);
+            if (below > want) break;                                  // m has at least `want` samples below or equal before it: the threshold
+            if (a == m) { a = b; b = c; c = d; d = 0xFFFFFFFFu; }     // the lanes that held it move on
+        }
+        if (tid == 0) ctl[4] = thr_v;
+    }
+    __syncthreads();
+    const uint32_t thr = ctl[4];
+    uint32_t take = 0;
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) take += u[e] <= thr ? 1u : 0u;     // (the filler never passes: thr is a real distance)
+    uint32_t base = take ? atomicAdd(&cnt, take) : 0u;
+    __syncthreads();
+    const uint32_t total = cnt;
+    if (total < k || total > 64 * BOOT_CUT_VPT) {                     // workgroup-uniform: the sample misjudged the row (or more than the cutting wave holds)
+        __syncthreads();
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        return false;
+    }
+#pragma unroll
+    for (int e = 0; e < VPT; ++e)
+        if (u[e] <= thr) keys[base++] = ((uint64_t)u[e] << 32) | (uint32_t)(nb_first + tid + e * THREADS);
+    __syncthreads();
+    return true;
+}
+
 // Before a merge is sorted: the k-th smallest distance among the n keys in LDS by radix selection, then only the keys at
 // or below it (k of them plus ties) move to the front -- the sort that orders them (and settles ties by id) runs on the next
 // power of two above k instead of above k + candidates (256 keys instead of 1024 at k = 200: a fifth of the work).
@@ -218,7 +289,7 @@ __device__ __forceinline__ void radix_cut(uint64_t *keys, uint32_t &cnt, uint32_
         u[e] = (uint32_t)(v[e] >> 32);
     }
     const uint32_t prefix = radix_kth<THREADS, VPT>(u, n, k, hist, ctl, tid);    // barriers inside: every key is in registers by now
-    if (tid == 0) cnt = 0;
+    if (tid == 0) { cnt = 0; ctl[3] = prefix; }                                   // (ctl[3]: the k-th distance, for a caller that leaves the keys unsorted)
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < VPT; ++e)
@@ -229,6 +300,107 @@ __device__ __forceinline__ void radix_cut(uint64_t *keys, uint32_t &cnt, uint32_
     while (n_sort < m) n_sort <<= 1;
     for (uint32_t i = m + tid; i < n_sort; i += THREADS) keys[i] = KEY_INF;     // the sort's padding
     __syncthreads();
+}
+
+// ---- merge by one WAVE per query (batches) -------------------------------------------------------------------------
+// The merge of a chunk's candidates into the running top-k is the step between two tile launches: with a 256-thread
+// workgroup per query its ~40 barrier-separated phases (histogram passes, sort steps) cost 19 us per call although the
+// work is a few hundred keys -- waves spent 58 % of their cycles parked (PMC).  Here a wave owns a query: the keys sit in
+// registers, the k-th smallest KEY (distance, then id: keys are unique, so exactly k survive and no plateau of ties needs a
+// special case) is found by radix selection over the bytes that actually differ (wave min / max first), and the survivors
+// go back to the state by ballot -- unsorted, no workgroup barrier anywhere.  (A first version also sorted them, in LDS:
+// one wave cannot hide the LDS round trip of 36 dependent sort stages and the kernel took 27 us.  Nothing needs the order
+// before the last chunk, whose merge sorts in select_one.)
+// A workgroup takes four queries; if any of them cannot go this way (candidate list overflowed -> exact rescan, first or
+// last chunk) the whole workgroup runs select_one() on its four queries in turn.
+constexpr uint32_t MW_VPT = SEL_CAP / 64;
+// The k smallest of n unique 64-bit keys held by one wave (slot e of lane l is element e * 64 + l < n; hi_at(e) / lo_at(e) yield
+// the distance word and the id word of its key) go to the state of query q, unordered; the k-th distance becomes the query's
+// threshold.  All tests run on the 32-bit halves (a pass over distance bytes never touches the ids).
+// `opaque`: a register lo_at() may depend on, made opaque once per pass (ids computed from the slot number would otherwise all be
+// formed ahead of the pass loop and kept).  (Tried for the 8192-row bootstrap as well, 128 computed keys per lane: 40 us against
+// the workgroup version's 32 -- one wave serialises on the few histogram bins the leading bytes fall into.)
+template <uint32_t VPT, class HiAt, class LoAt>
+__device__ __forceinline__ void wave_keep_k_smallest(const SelArgs &p, const size_t q, uint32_t n, uint32_t *hist, int lane, uint32_t &opaque,
+                                                     HiAt &&hi_at, LoAt &&lo_at) {
+    const uint32_t k = p.k;
+    uint32_t Thi = (uint32_t)((KEY_INF - 1) >> 32), Tlo = (uint32_t)(KEY_INF - 1);     // keep every real key when there are no more than k
+    if (n > k) {
+        // bits in which the keys differ at all: OR over (key ^ one of the keys); the bytes above the first of them are common
+        const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi_at(0)), l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo_at(0));
+        uint32_t dl = 0, dh = 0;                                    // (lane 0 holds a real key: n > k >= 1)
+#pragma unroll
+        for (uint32_t e = 0; e < VPT; ++e)
+            if (e * 64 < n && e * 64 + lane < n) { dh |= hi_at(e) ^ h_first; dl |= lo_at(e) ^ l_first; }
+        dh = __reduce_or_sync(~0ull, dh); dl = __reduce_or_sync(~0ull, dl);            // not both zero: keys are unique
+        int shift = dh ? 32 + ((31 - __builtin_clz(dh)) / 8) * 8 : ((31 - __builtin_clz(dl | 1u)) / 8) * 8;
+        // prefix / mask of the bytes already fixed, as (distance word, id word)
+        uint32_t p_hi, m_hi, p_lo = 0, m_lo = 0;
+        if (shift >= 32) { const int s2 = shift - 32; m_hi = s2 >= 24 ? 0u : ~0u << (s2 + 8); p_hi = h_first & m_hi; }
+        else { m_hi = ~0u; p_hi = h_first; m_lo = shift >= 24 ? 0u : ~0u << (shift + 8); p_lo = l_first & m_lo; }
+        uint32_t need = k;
+        for (;; shift -= 8) {
+            asm volatile("" : "+v"(opaque));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
+            wave_sync();
+            if (shift >= 32) {                                      // wave-uniform: a byte of the distance
+                const int s2 = shift - 32;
+#pragma unroll
+                for (uint32_t e = 0; e < VPT; ++e)
+                    if (e * 64 < n && e * 64 + lane < n) { const uint32_t h = hi_at(e); if ((h & m_hi) == p_hi) atomicAdd(&hist[(h >> s2) & 255u], 1u); }
+            } else {                                                // a byte of the id: only among keys of the k-th distance
+#pragma unroll
+                for (uint32_t e = 0; e < VPT; ++e)
+                    if (e * 64 < n && e * 64 + lane < n && hi_at(e) == p_hi) { const uint32_t l = lo_at(e); if ((l & m_lo) == p_lo) atomicAdd(&hist[(l >> shift) & 255u], 1u); }
+            }
+            wave_sync();
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t incl = wave_incl_scan(h0 + h1 + h2 + h3);
+            const int L = __builtin_ctzll(__ballot(incl >= need));          // the lane whose four bins hold the need-th key (wave-uniform)
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, L), b1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, L),
+                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)h2, L), b3 = (uint32_t)__builtin_amdgcn_readlane((int)h3, L);
+            uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (b0 + b1 + b2 + b3);
+            uint32_t bin = 4 * L, cnt_bin = b0;
+            if (cum + b0 < need) { cum += b0; ++bin; cnt_bin = b1;
+                if (cum + b1 < need) { cum += b1; ++bin; cnt_bin = b2;
+                    if (cum + b2 < need) { cum += b2; ++bin; cnt_bin = b3; } } }
+            need -= cum;
+            if (shift >= 32) { p_hi |= bin << (shift - 32); m_hi |= 0xFFu << (shift - 32); }
+            else { p_lo |= bin << shift; m_lo |= 0xFFu << shift; }
+            if (cnt_bin == need || shift == 0) {                   // the whole bin is wanted (always so at the last byte: keys are unique)
+                Thi = p_hi | ~m_hi; Tlo = p_lo | ~m_lo;
+                break;
+            }
+        }
+    }
+    asm volatile("" : "+v"(opaque));
+    // compaction: keys <= T go to the state, by ballot -- UNSORTED (nothing between two chunks needs the order: the next
+    // merge selects again, the tile kernel only wants the k-th distance; the last chunk's merge sorts, in select_one)
+    uint32_t total = 0, dmax = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < VPT; ++e) {
+        if (e * 64 < n) {
+            const uint32_t h = hi_at(e), l = lo_at(e);
+            const bool keep = e * 64 + lane < n && (h < Thi || (h == Thi && l <= Tlo));
+            const uint64_t m = __ballot(keep);
+            const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (keep && pos < k) {
+                p.state[q * k + pos] = ((uint64_t)h << 32) | l;
+                dmax = h > dmax ? h : dmax;
+            }
+            total += (uint32_t)__popcll(m);
+        }
+    }
+    total = total < k ? total : k;                                  // (unique keys: exactly min(n, k))
+    // the k-th distance: largest kept one (six ds_bpermute steps on one word, once)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(dmax, d); dmax = o > dmax ? o : dmax; }
+    if (lane == 0) {
+        p.state_cnt[q] = total;
+        p.tau[q] = total == k ? __uint_as_float(dmax) : INFINITY;   // distances are >= 0: their bit patterns order like the values
+        p.cand_cnt[q] = 0;
+    }
 }
 
 // One workgroup per query.  mode 0: scan the chunk's slab.  mode 1: merge the filtered candidates into the
@@ -258,8 +430,31 @@ __device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
     __syncthreads();
     __shared__ uint32_t hist[256], ctl[20];
     bool done = false;
-    if (p.mode == 0 && c0 == 0 && p.nb_count > k && p.nb_count <= 8192)               // first chunk, more rows than results
-        done = radix_bootstrap<THREADS>(keys, cnt, hist, ctl, k, p.slab + q * (size_t)p.slab_ld, p.nb_first, (uint32_t)p.nb_count, tid);
+    if (p.mode == 0 && c0 == 0 && p.nb_count > k && p.nb_count <= 8192) {             // first chunk, more rows than results
+        // batches on exact operands, more chunks to come: the sampled threshold + a cut of its few hundred survivors (the state may stay unsorted)
+        if constexpr (THREADS == 256) {
+            if (!p.last && !(p.q_flags && (!p.base_exact || (p.q_flags[q / 128] & 1u)))) {        // workgroup-uniform
+                done = sample_bootstrap<THREADS>(keys, cnt, hist, ctl, k, p.slab + q * (size_t)p.slab_ld, p.nb_first, (uint32_t)p.nb_count, tid);
+#if defined(PF_ABL_SEL_STAGE) && PF_ABL_SEL_STAGE <= 2   // ablation (timing only, wrong results): no cut, nothing written
+                if (done) return;
+#endif
+                if (done) {
+                    // the few hundred keys the threshold let through are cut to the k smallest by ONE wave, in registers (the merge's selection: no
+                    // workgroup barrier; the four-pass radix cut of the whole workgroup is sixteen barriers for this handful of keys)
+                    if (tid < 64) {
+                        const uint32_t n = cnt;
+                        uint64_t v[BOOT_CUT_VPT];
+#pragma unroll
+                        for (uint32_t e = 0; e < BOOT_CUT_VPT; ++e) v[e] = (e * 64 < n && e * 64 + tid < n) ? keys[e * 64 + tid] : KEY_INF;
+                        uint32_t unused = 0;
+                        wave_keep_k_smallest<BOOT_CUT_VPT>(p, q, n, hist, tid, unused, [&](uint32_t e) { return (uint32_t)(v[e] >> 32); }, [&](uint32_t e) { return (uint32_t)v[e]; });
+                    }
+                    return;
+                }
+            }
+        }
+        if (!done) done = radix_bootstrap<THREADS>(keys, cnt, hist, ctl, k, p.slab + q * (size_t)p.slab_ld, p.nb_first, (uint32_t)p.nb_count, tid);
+    }
     // Batches (256 threads: every later merge is merge_wave or the full sort of the last chunk, neither assumes an ordered state): when exactly k keys came
     // back -- no ties at the k-th distance to cut by id -- the bootstrap's state goes out as it is, unsorted; the sort below was 6 of this kernel's 30 us.
     // (Inexact operands keep it: the density estimate below reads the sorted keys.)
@@ -369,107 +564,6 @@ __device__ __forceinline__ void select_one(const SelArgs &p, const size_t q) {
 
 template <uint32_t THREADS>
 __global__ void __launch_bounds__(THREADS) k_select(SelArgs p) { select_one<THREADS>(p, blockIdx.x); }
-
-// ---- merge by one WAVE per query (batches) -------------------------------------------------------------------------
-// The merge of a chunk's candidates into the running top-k is the step between two tile launches: with a 256-thread
-// workgroup per query its ~40 barrier-separated phases (histogram passes, sort steps) cost 19 us per call although the
-// work is a few hundred keys -- waves spent 58 % of their cycles parked (PMC).  Here a wave owns a query: the keys sit in
-// registers, the k-th smallest KEY (distance, then id: keys are unique, so exactly k survive and no plateau of ties needs a
-// special case) is found by radix selection over the bytes that actually differ (wave min / max first), and the survivors
-// go back to the state by ballot -- unsorted, no workgroup barrier anywhere.  (A first version also sorted them, in LDS:
-// one wave cannot hide the LDS round trip of 36 dependent sort stages and the kernel took 27 us.  Nothing needs the order
-// before the last chunk, whose merge sorts in select_one.)
-// A workgroup takes four queries; if any of them cannot go this way (candidate list overflowed -> exact rescan, first or
-// last chunk) the whole workgroup runs select_one() on its four queries in turn.
-constexpr uint32_t MW_VPT = SEL_CAP / 64;
-// The k smallest of n unique 64-bit keys held by one wave (slot e of lane l is element e * 64 + l < n; hi_at(e) / lo_at(e) yield
-// the distance word and the id word of its key) go to the state of query q, unordered; the k-th distance becomes the query's
-// threshold.  All tests run on the 32-bit halves (a pass over distance bytes never touches the ids).
-// `opaque`: a register lo_at() may depend on, made opaque once per pass (ids computed from the slot number would otherwise all be
-// formed ahead of the pass loop and kept).  (Tried for the 8192-row bootstrap as well, 128 computed keys per lane: 40 us against
-// the workgroup version's 32 -- one wave serialises on the few histogram bins the leading bytes fall into.)
-template <uint32_t VPT, class HiAt, class LoAt>
-__device__ __forceinline__ void wave_keep_k_smallest(const SelArgs &p, const size_t q, uint32_t n, uint32_t *hist, int lane, uint32_t &opaque,
-                                                     HiAt &&hi_at, LoAt &&lo_at) {
-    const uint32_t k = p.k;
-    uint32_t Thi = (uint32_t)((KEY_INF - 1) >> 32), Tlo = (uint32_t)(KEY_INF - 1);     // keep every real key when there are no more than k
-    if (n > k) {
-        // bits in which the keys differ at all: OR over (key ^ one of the keys); the bytes above the first of them are common
-        const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi_at(0)), l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo_at(0));
-        uint32_t dl = 0, dh = 0;                                    // (lane 0 holds a real key: n > k >= 1)
-#pragma unroll
-        for (uint32_t e = 0; e < VPT; ++e)
-            if (e * 64 < n && e * 64 + lane < n) { dh |= hi_at(e) ^ h_first; dl |= lo_at(e) ^ l_first; }
-        dh = __reduce_or_sync(~0ull, dh); dl = __reduce_or_sync(~0ull, dl);            // not both zero: keys are unique
-        int shift = dh ? 32 + ((31 - __builtin_clz(dh)) / 8) * 8 : ((31 - __builtin_clz(dl | 1u)) / 8) * 8;
-        // prefix / mask of the bytes already fixed, as (distance word, id word)
-        uint32_t p_hi, m_hi, p_lo = 0, m_lo = 0;
-        if (shift >= 32) { const int s2 = shift - 32; m_hi = s2 >= 24 ? 0u : ~0u << (s2 + 8); p_hi = h_first & m_hi; }
-        else { m_hi = ~0u; p_hi = h_first; m_lo = shift >= 24 ? 0u : ~0u << (shift + 8); p_lo = l_first & m_lo; }
-        uint32_t need = k;
-        for (;; shift -= 8) {
-            asm volatile("" : "+v"(opaque));
-#pragma unroll
-            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
-            wave_sync();
-            if (shift >= 32) {                                      // wave-uniform: a byte of the distance
-                const int s2 = shift - 32;
-#pragma unroll
-                for (uint32_t e = 0; e < VPT; ++e)
-                    if (e * 64 < n && e * 64 + lane < n) { const uint32_t h = hi_at(e); if ((h & m_hi) == p_hi) atomicAdd(&hist[(h >> s2) & 255u], 1u); }
-            } else {                                                // a byte of the id: only among keys of the k-th distance
-#pragma unroll
-                for (uint32_t e = 0; e < VPT; ++e)
-                    if (e * 64 < n && e * 64 + lane < n && hi_at(e) == p_hi) { const uint32_t l = lo_at(e); if ((l & m_lo) == p_lo) atomicAdd(&hist[(l >> shift) & 255u], 1u); }
-            }
-            wave_sync();
-            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-            const uint32_t incl = wave_incl_scan(h0 + h1 + h2 + h3);
-            const int L = __builtin_ctzll(__ballot(incl >= need));          // the lane whose four bins hold the need-th key (wave-uniform)
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, L), b1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, L),
-                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)h2, L), b3 = (uint32_t)__builtin_amdgcn_readlane((int)h3, L);
-            uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (b0 + b1 + b2 + b3);
-            uint32_t bin = 4 * L, cnt_bin = b0;
-            if (cum + b0 < need) { cum += b0; ++bin; cnt_bin = b1;
-                if (cum + b1 < need) { cum += b1; ++bin; cnt_bin = b2;
-                    if (cum + b2 < need) { cum += b2; ++bin; cnt_bin = b3; } } }
-            need -= cum;
-            if (shift >= 32) { p_hi |= bin << (shift - 32); m_hi |= 0xFFu << (shift - 32); }
-            else { p_lo |= bin << shift; m_lo |= 0xFFu << shift; }
-            if (cnt_bin == need || shift == 0) {                   // the whole bin is wanted (always so at the last byte: keys are unique)
-                Thi = p_hi | ~m_hi; Tlo = p_lo | ~m_lo;
-                break;
-            }
-        }
-    }
-    asm volatile("" : "+v"(opaque));
-    // compaction: keys <= T go to the state, by ballot -- UNSORTED (nothing between two chunks needs the order: the next
-    // merge selects again, the tile kernel only wants the k-th distance; the last chunk's merge sorts, in select_one)
-    uint32_t total = 0, dmax = 0;
-#pragma unroll
-    for (uint32_t e = 0; e < VPT; ++e) {
-        if (e * 64 < n) {
-            const uint32_t h = hi_at(e), l = lo_at(e);
-            const bool keep = e * 64 + lane < n && (h < Thi || (h == Thi && l <= Tlo));
-            const uint64_t m = __ballot(keep);
-            const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (keep && pos < k) {
-                p.state[q * k + pos] = ((uint64_t)h << 32) | l;
-                dmax = h > dmax ? h : dmax;
-            }
-            total += (uint32_t)__popcll(m);
-        }
-    }
-    total = total < k ? total : k;                                  // (unique keys: exactly min(n, k))
-    // the k-th distance: largest kept one (six ds_bpermute steps on one word, once)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(dmax, d); dmax = o > dmax ? o : dmax; }
-    if (lane == 0) {
-        p.state_cnt[q] = total;
-        p.tau[q] = total == k ? __uint_as_float(dmax) : INFINITY;   // distances are >= 0: their bit patterns order like the values
-        p.cand_cnt[q] = 0;
-    }
-}
 
 // merge of a chunk's candidates into the running state
 __device__ __forceinline__ void merge_wave(const SelArgs &p, const size_t q, uint32_t *hist, int lane) {

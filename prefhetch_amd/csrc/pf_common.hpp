@@ -10,7 +10,7 @@
 // Makefile hashes $(EXTRA) into BUILD), reports itself through pf_build_flags() and is refused by the Python loader unless it was
 // asked for by path (PREFHETCH_HIP_LIB).  A default `make` can therefore never link an ablation object into lib/libprefhetch_hip.so.
 #if defined(PF_ABL_NOEMIT) || defined(PF_ABL_NODMA) || defined(PF_ABL_NOSURV) || defined(PF_ABL_NOBAR) || defined(PF_ABL_NODRAIN) || \
-    defined(PF_ABL_EXACTFLUSH) || defined(PF_ABL_I8ONLY) || defined(PF_FLAT_STAMPS) || defined(PF_DEV_ONLY_D128) || defined(PF_ABL_W8_HOTB)
+    defined(PF_ABL_EXACTFLUSH) || defined(PF_ABL_I8ONLY) || defined(PF_FLAT_STAMPS) || defined(PF_DEV_ONLY_D128) || defined(PF_ABL_W8_HOTB) || defined(PF_ABL_SEL_STAGE)
 #define PF_HAS_EXPERIMENT_SWITCH 1
 #ifndef PF_EXPERIMENT_BUILD
 #error "PF_ABL_* / PF_FLAT_STAMPS are experiment switches (wrong results / debug buffers): add -DPF_EXPERIMENT_BUILD and build into a directory of its own"

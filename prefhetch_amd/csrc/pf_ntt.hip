@@ -311,7 +311,8 @@ pf_status run_ns_split(pf_ctx *c, int op, const uint64_t *src, uint64_t *dst, co
 
 pf_status pf_ntt_forward_to(pf_ctx *c, const uint64_t *src, uint64_t *dst, size_t n, pf_stream stream) {
     if (!c || ((!src || !dst) && n)) return fail(PF_ERR_INVALID_ARG, "null argument");
-    if (c->ns_ok(0) && n % c->L == 0) return run_ns_split(c, 0, src, dst, nullptr, false, n, stream);
+    if (c->ns_ok(0) && n % c->L == 0 && src == dst) return run_ns_split(c, 0,      // (in place only: out of place the split measured 2.00 ms against 1.93)
+        src, dst, nullptr, false, n, stream);
     NttArgs a{c->d_limbs, c->d_tables, src, dst, nullptr, 0, c->L, 0, 0};
     return run_ntt_like(c, 0, 0, a, n, stream);
 }

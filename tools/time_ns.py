@@ -26,4 +26,4 @@ L = len(QS)
 for name, fn, nbytes in (("ct_x_pt", lambda: ctx.ct_pt_mul(ct, pt, out=res), 40 * L * N * B), ("forward", lambda: ctx.ntt_forward_(res), 32 * L * N * B),
                          ("inverse", lambda: ctx.ntt_inverse_(res), 32 * L * N * B)):
     ms = timed(fn)
-    print("%-8s %.3f ms  %.3f of 8 TB/s   split=%s round=%s" % (name, ms, nbytes / (ms * 1e-3) / 8e12, os.environ.get("PF_NS_SPLIT", "1"), os.environ.get("PF_NS_ROUND", "480")))
+    print("%-8s %.3f ms  %.3f of 8 TB/s   split=%s round=%s" % (name, ms, nbytes / (ms * 1e-3) / 8e12, os.environ.get("PF_NS_SPLIT", "1"), os.environ.get("PF_NS_ROUND", "960 (default)")))
