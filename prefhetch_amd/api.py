@@ -291,7 +291,7 @@ class FlatL2:
 
     def operands8(self, mode=-1):
         """int8 tiles of the batch pre-filter (pf_flat_operands8): mode 1 on (default), 0 off, -1 query.  True when the base is 8-bit data
-        (every value an integer in [0, 255], d a multiple of 32 up to 128), its int8 image exists and the path is on."""
+        (every value an integer in [0, 255], d up to 128 and a multiple of 32 or not a multiple of 16 -- then padded to one), its int8 image exists and the path is on."""
         a = C.c_int()
         check(lib.pf_flat_operands8(self._h, int(mode), C.byref(a)), "pf_flat_operands8")
         return bool(a.value)

@@ -225,12 +225,17 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             constexpr uint32_t X_ALL = 2u * BUF >= 128u * XP ? 128u : 64u, X_ONE = BUF >= 128u * XP ? 128u : BUF >= 64u * XP ? 64u : 32u;
             static_assert(2u * BUF >= X_ALL * XP && BUF >= X_ONE * XP, "the staged query rows fit the tile buffers");
             const uint32_t XROWS = final ? X_ALL : X_ONE;
+            // (the fp32 rows have p.d values; D is the images' row length, p.d padded with zeros.  Rows whose length is not a multiple of 4 are not
+            // 16-byte aligned: they are read value by value.)
+            const uint32_t dv = p.d;
+            const bool vec4 = (dv & 3u) == 0;
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;
                 pd.rcnt[tid] = 0;
             }
-            if constexpr (PF_APPROX_SLABS && LAST && D % 64 == 0 && (((2u * BUF) / 4u) & ~15u) >= 16384u) {       // (two 8 KiB slab buffers per wave: rows of 128 and of 256 values)
+            constexpr bool SLABS_OK = PF_APPROX_SLABS && LAST && D % 64 == 0 && (((2u * BUF) / 4u) & ~15u) >= 16384u;
+            if (SLABS_OK && dv == (uint32_t)D) {                          // (a compile-time false unless the experiment is switched on)
                 // The walk's last flush (both tile buffers free).  One lane per survivor reading its own two rows from memory made the texture path
                 // see 64 different cache lines per load instruction: 82 us of a search on N(0,1) data (round 3's ablation).  Now every WAVE takes 64
                 // survivors at a time and walks their rows in slabs of 16 values: the slab's 64-byte pieces of the 64 query rows and the 64 base rows
@@ -292,10 +297,18 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             for (uint32_t r0 = 0; r0 < (xstage ? 128u : 1u); r0 += XROWS) {           // (without staging: one round over everything)
                 if (xstage) {
                     if (r0) __syncthreads();                              // the first half's readers are done
-                    for (uint32_t i = tid; i < XROWS * (D / 4); i += 256) {
-                        const uint32_t row = r0 + i / (D / 4), seg = i % (D / 4);
-                        *reinterpret_cast<float4 *>(xstage + (row - r0) * XP + seg * 16) =
-                            reinterpret_cast<const float4 *>(p.xq + (q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)D)[seg];
+                    if (vec4) {
+                        const uint32_t segs = dv / 4;
+                        for (uint32_t i = tid; i < XROWS * segs; i += 256) {
+                            const uint32_t row = r0 + i / segs, seg = i % segs;
+                            *reinterpret_cast<float4 *>(xstage + (row - r0) * XP + seg * 16) =
+                                reinterpret_cast<const float4 *>(p.xq + (q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)dv)[seg];
+                        }
+                    } else {
+                        for (uint32_t i = tid; i < XROWS * dv; i += 256) {
+                            const uint32_t row = r0 + i / dv, t = i % dv;
+                            reinterpret_cast<float *>(xstage + (row - r0) * XP)[t] = p.xq[(q0 + (row < q_valid ? row : q_valid - 1)) * (size_t)dv + t];
+                        }
                     }
                 }
                 __syncthreads();
@@ -304,21 +317,42 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
                     if (xstage && (row < r0 || row >= r0 + XROWS)) continue;
                     const uint32_t pos = atomicAdd(&pd.rbase[row], 1u);
                     if (pos >= p.cap) continue;                           // the list of this query overflowed: k_select rescans the chunk
-                    const float4 *y = reinterpret_cast<const float4 *>(p.xb + (size_t)id * D);
+                    const float *yr = p.xb + (size_t)id * dv;
+                    const float4 *y = reinterpret_cast<const float4 *>(yr);
                     float acc = 0.f;
-                    if (xstage) {
+                    if (!vec4) {                                          // workgroup-uniform: odd row lengths, value by value (same k-ordered chain)
+                        const float *x = xstage ? reinterpret_cast<const float *>(xstage + (row - r0) * XP) : p.xq + (q0 + row) * (size_t)dv;
+#pragma unroll 16
+                        for (uint32_t t = 0; t < dv; ++t) acc = fmaf(x[t], yr[t], acc);
+                    } else if (xstage) {
                         const float4 *x = reinterpret_cast<const float4 *>(xstage + (row - r0) * XP);
+                        if (dv == (uint32_t)D) {
 #pragma unroll PF_APPROX_UNROLL
-                        for (int t = 0; t < D / 4; ++t) {
-                            const float4 a = x[t], b = y[t];
-                            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            for (int t = 0; t < D / 4; ++t) {
+                                const float4 a = x[t], b = y[t];
+                                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            }
+                        } else {
+#pragma unroll 8
+                            for (uint32_t t = 0; t < dv / 4; ++t) {
+                                const float4 a = x[t], b = y[t];
+                                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            }
                         }
                     } else {
-                        const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)D);
+                        const float4 *x = reinterpret_cast<const float4 *>(p.xq + (q0 + row) * (size_t)dv);
+                        if (dv == (uint32_t)D) {
 #pragma unroll PF_APPROX_UNROLL2
-                        for (int t = 0; t < D / 4; ++t) {
-                            const float4 a = x[t], b = y[t];
-                            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            for (int t = 0; t < D / 4; ++t) {
+                                const float4 a = x[t], b = y[t];
+                                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            }
+                        } else {
+#pragma unroll 8
+                            for (uint32_t t = 0; t < dv / 4; ++t) {
+                                const float4 a = x[t], b = y[t];
+                                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                            }
                         }
                     }
                     const float dist = fmaf(-2.f, acc, sA[2 * row] + p.bn[id]);

@@ -27,7 +27,12 @@ template <uint32_t ROWS, uint32_t MAXD>
 __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ norms,
                                                   uint16_t *__restrict__ x16, uint32_t pitch16, bool aux, uint32_t *__restrict__ inexact,
                                                   uint32_t rows_per_flag, int8_t *__restrict__ x8 = nullptr, uint32_t pitch8 = 0,
-                                                  int8_t *__restrict__ x8f = nullptr, int *__restrict__ c0f = nullptr, int *__restrict__ sx8 = nullptr) {
+                                                  int8_t *__restrict__ x8f = nullptr, int *__restrict__ c0f = nullptr, int *__restrict__ sx8 = nullptr,
+                                                  uint32_t dp = 0) {
+    // dp (0: d): the row length of the IMAGES -- d padded with zeros (value 0: the byte -128 in the 8-bit images) to whole k-steps of the matrix
+    // instructions, so that every row length takes the tile path.  A zero contributes nothing to a dot product or a norm, and the integer algebra of
+    // the 8-bit filter holds for the padded vectors as it does for any others (its constants are taken at dp).
+    dp = dp ? dp : d;
     __shared__ float tile[ROWS * (MAXD + 1)];
     const size_t r0 = (size_t)blockIdx.x * ROWS;
     const uint32_t rows = (uint32_t)(n - r0 < ROWS ? n - r0 : ROWS), total = rows * d, lane = threadIdx.x;
@@ -44,8 +49,19 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             const bool ok8 = v == rintf(v) && v >= 0.f && v <= 255.f;
             const int8_t b8 = (int8_t)(ok8 ? (int)v - 128 : 0);
             x8[(r0 + r) * (size_t)pitch8 + k] = b8;
-            if (x8f) x8f[frag8_offset(r0 + r, k, frag8_ksteps(d))] = b8;                      // the same byte in the streamed walk's operand order (flat_common.hpp)
+            if (x8f) x8f[frag8_offset(r0 + r, k, frag8_ksteps(dp))] = b8;                     // the same byte in the streamed walk's operand order (flat_common.hpp)
             if (!ok8) bad8 |= fbit;
+        }
+    }
+    if (dp > d) {                                                 // the padding of this block's rows (the queries' images live in a reused workspace: written every time)
+        const uint32_t pad = dp - d;
+        for (uint32_t e = lane; e < rows * pad; e += 64) {
+            const uint32_t r = e / pad, k = d + (e - r * pad);
+            if (x16) x16[(r0 + r) * pitch16 + k] = 0;
+            if (x8) {
+                x8[(r0 + r) * (size_t)pitch8 + k] = (int8_t)-128;
+                if (x8f) x8f[frag8_offset(r0 + r, k, frag8_ksteps(dp))] = (int8_t)-128;
+            }
         }
     }
     if (bad | bad8) {                                             // a block of <= 64 rows touches at most two flags (rows_per_flag >= 64) or one
@@ -67,19 +83,19 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             w[1] = (b[2] ^ BF16_SIGN) | (BF16_ONE << 16);
             w[2] = BF16_ONE | (BF16_ONE << 16);
             w[3] = 0;
-            *reinterpret_cast<u32x4 *>(x16 + (r0 + lane) * pitch16 + d) = w;        // 16-byte aligned: d and pitch16 are multiples of 8
+            *reinterpret_cast<u32x4 *>(x16 + (r0 + lane) * pitch16 + dp) = w;       // 16-byte aligned: dp and pitch16 are multiples of 8
         }
         if (x8 && aux) {                                         // the column's half of the integer threshold (tile16_walk): c0 = -floor(C / 2), C = |y|^2 - 256 sum (y - 128)
-            int sy = 0;
+            int sy = -128 * (int)(dp - d);                           // (the padding: value 0 = -128)
             for (uint32_t k = 0; k < d; ++k) sy += (int)row[k] - 128;
             const int Cc = (int)acc - 256 * sy;
             u32x4 w;
             w[0] = (uint32_t)(-(Cc >> 1)); w[1] = (uint32_t)sy; w[2] = 0; w[3] = 0;      // (sum y' for the unfiltered launch, which forms distances)
-            *reinterpret_cast<u32x4 *>(x8 + (r0 + lane) * (size_t)pitch8 + d) = w;   // 16-byte aligned: d and pitch8 are multiples of 16
+            *reinterpret_cast<u32x4 *>(x8 + (r0 + lane) * (size_t)pitch8 + dp) = w;  // 16-byte aligned: dp and pitch8 are multiples of 16
             if (c0f) c0f[frag8_c0_index(r0 + lane)] = Cc;                               // C itself: the walk halves it, the flush forms distances with it
         }
         if (x8 && !aux && sx8) {                                 // queries: sum (x - 128), the row half of the integer threshold needs it (tile8_walk)
-            int s = 0;
+            int s = -128 * (int)(dp - d);
             for (uint32_t k = 0; k < d; ++k) s += (int)row[k] - 128;
             sx8[r0 + lane] = s;
         }
@@ -90,7 +106,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
 // (k_l2_tile16: the bound on the operands' rounding is (2^-8 + 2^-17)(|x|^2 + |y|^2), priced per column -- a base whose rows
 // differ widely in length would otherwise pay the longest row's margin in every column).
 constexpr float BF16_MARGIN = 1.05f * 0x1p-8f;
-__global__ void __launch_bounds__(256) k_aux_margin(uint16_t *__restrict__ x16, const float *__restrict__ norms, size_t n, uint32_t d, uint32_t pitch16) {
+__global__ void __launch_bounds__(256) k_aux_margin(uint16_t *__restrict__ x16, const float *__restrict__ norms, size_t n, uint32_t d /* image row length */, uint32_t pitch16) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     uint32_t b[3];

@@ -71,7 +71,8 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
     const bool approx = !I8 && (!p.base_exact || (qflags & 1u));    // (qflags: workgroup-uniform; the caller picked I8 for exact 8-bit operands only)
     if (!I8 && ((!FILTER && approx) || (FILTER && (qflags & 2u)))) {
         for (uint32_t ct = ct0; ct < ct1; ++ct) {
-            l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
+            if (p.d % TK == 0) l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);        // workgroup-uniform (a padded row length has the bounds-checked slab fetch)
+            else l2_tile_f32<FILTER, GEO, false, false>(p, smem, qt, ct);
             __syncthreads();
         }
         return;

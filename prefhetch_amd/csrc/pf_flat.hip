@@ -89,6 +89,7 @@ struct pf_flat {
     int device = 0;
     size_t nb = 0;
     uint32_t d = 0;
+    uint32_t dp = 0;              // row length of the operand images: d, or d padded with zeros to whole k-steps (image_row_length)
     float *xb = nullptr, *bn = nullptr;
     uint16_t *xb16 = nullptr;     // bf16 image of the base matrix (d = 64 or 128): rows of d values + AUX16 threshold words, nearest-even
     bool exact16 = false;         // EVERY value of the base passed the on-device exactness check: the image is the matrix itself
@@ -117,9 +118,18 @@ namespace {
 #endif
 constexpr size_t BOOT_ROWS = PF_BOOT_ROWS;  // bootstrap chunk (slab path); at most 8192 (radix_bootstrap keeps the chunk in registers)
 
+// Row length of the 16-bit / 8-bit operand images for rows of d values: every d up to 256 takes the tile path.  A row length the matrix
+// instructions take as it is (a multiple of 16) stays; any other is padded with zeros -- to a multiple of 32 up to 128 values (the int8 tiles'
+// k-step, so that 8-bit data of any row length runs them), of 16 beyond.  0: no image (d above 256).
+uint32_t image_row_length(uint32_t d) {
+    if (d > 256) return 0;
+    if (d % 16 == 0) return d;
+    return d <= 128 ? (d + 31) / 32 * 32 : (d + 15) / 16 * 16;
+}
+
 struct WsPlan { size_t boot, slab_ld, cap, off_qn, off_tau, off_cnt, off_scnt, off_state, off_cand, off_slab, off_q16, off_q8, off_qsx, off_qbad, total; };
 
-WsPlan plan_ws(size_t nb, size_t nq, uint32_t k, uint32_t d) {
+WsPlan plan_ws(size_t nb, size_t nq, uint32_t k, uint32_t d /* image row length, or d */) {
     WsPlan w{};
     const size_t nb_pad = (nb + 127) / 128 * 128;
     w.boot = BOOT_ROWS < nb_pad ? BOOT_ROWS : (nb_pad ? nb_pad : 128);
@@ -188,7 +198,8 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PF_ERR_NO_DEVICE, "no such HIP device");
     PF_GUARD(device);
     pf_flat *f = new pf_flat;
-    f->device = device; f->nb = nb; f->d = d;
+    f->device = device; f->nb = nb; f->d = d; f->dp = image_row_length(d);
+    const uint32_t dp = f->dp;
     if (const char *v = getenv("PF_FLAT_B16_MIN_NQ")) f->b16_min_nq = (size_t)atoi(v);
     if (const char *v = getenv("PF_FLAT_GROUP_CAP")) { if (atoi(v) > 0) f->group_cap = (size_t)atoi(v); }
     if (const char *v = getenv("PF_FLAT_GROWTH_DIV")) f->growth_div = atof(v);
@@ -202,9 +213,9 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
         uint32_t *flag = nullptr;
         // every row length that is a multiple of the matrix instruction's k-step up to 256 (k_rows_prep stages whole rows in LDS
         // up to PREP_MAX_D; beyond 128 values the tiles are 128 x 64: Geo16W)
-        const bool try16 = d % 16 == 0 && d <= 256 && getenv("PF_FLAT_NO_BF16") == nullptr;
+        const bool try16 = dp != 0 && getenv("PF_FLAT_NO_BF16") == nullptr;
         // image rows carry AUX16 threshold words behind their d values; one tile of zero rows pads the end (k_l2_tile16 copies whole tiles)
-        const size_t bytes16 = (nb + 128) * (size_t)(d + AUX16) * 2;
+        const size_t bytes16 = (nb + 128) * (size_t)(dp + AUX16) * 2;
         if (try16 && (hipMalloc((void **)&f->xb16, bytes16) != hipSuccess || hipMemset(f->xb16, 0, bytes16) != hipSuccess ||
                       hipMalloc((void **)&flag, 4) != hipSuccess || hipMemset(flag, 0, 4) != hipSuccess)) {
             (void)hipGetLastError();                                  // no room for the image: the fp32 path needs none
@@ -213,23 +224,24 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
         }
         // 8-bit data (SIFT, the reference's dataset): an int8 image for the integer matrix instruction where the rows are whole 32-deep k-steps
         // (same zero-row padding; rows of d values - 128 + AUX8 bytes).  Kept only if EVERY value is an integer in [0, 255] (flag bit 2).
-        const size_t bytes8 = (nb + 128) * (size_t)(d + AUX8);
-        if (f->xb16 && d % 32 == 0 && d <= 128 && getenv("PF_FLAT_NO_I8") == nullptr &&
+        const size_t bytes8 = (nb + 128) * (size_t)(dp + AUX8);
+        if (f->xb16 && dp % 32 == 0 && dp <= 128 && getenv("PF_FLAT_NO_I8") == nullptr &&
             (hipMalloc((void **)&f->xb8, bytes8) != hipSuccess || hipMemset(f->xb8, 0, bytes8) != hipSuccess)) {
             (void)hipGetLastError();
             if (f->xb8) { (void)hipFree(f->xb8); f->xb8 = nullptr; }
         }
         // the fragment-order image: whole steps of 32 rows, two steps of zero rows behind the end (a walk prefetches one step ahead, clamped to its last)
-        const size_t rows8f = (nb + 31) / 32 * 32 + 64, bytes8f = rows8f / 16 * frag8_ksteps(d) * 1024, bytesc0 = rows8f * sizeof(int);
+        const size_t rows8f = (nb + 31) / 32 * 32 + 64, bytes8f = rows8f / 16 * frag8_ksteps(dp) * 1024, bytesc0 = rows8f * sizeof(int);
         if (f->xb8 && (hipMalloc((void **)&f->xb8f, bytes8f) != hipSuccess || hipMemset(f->xb8f, 0, bytes8f) != hipSuccess ||
                        hipMalloc((void **)&f->c0f, bytesc0) != hipSuccess || hipMemset(f->c0f, 0, bytesc0) != hipSuccess)) {
             (void)hipGetLastError();
             if (f->xb8f) { (void)hipFree(f->xb8f); f->xb8f = nullptr; }
             if (f->c0f) { (void)hipFree(f->c0f); f->c0f = nullptr; }
         }
-        if (d <= 128) hipLaunchKernelGGL((k_rows_prep<64, 128>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u,
-                                         f->xb8, d + (uint32_t)AUX8, f->c0f ? f->xb8f : nullptr, f->c0f, (int *)nullptr);
-        else if (d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<32, PREP_MAX_D>), dim3((unsigned)((nb + 31) / 32)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, d + AUX16, true, flag, 0u);
+        if (d <= 128) hipLaunchKernelGGL((k_rows_prep<64, 128>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, dp + AUX16, true, flag, 0u,
+                                         f->xb8, dp + (uint32_t)AUX8, f->c0f ? f->xb8f : nullptr, f->c0f, (int *)nullptr, dp);
+        else if (d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<32, PREP_MAX_D>), dim3((unsigned)((nb + 31) / 32)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, dp + AUX16, true, flag, 0u,
+                                                     (int8_t *)nullptr, 0u, (int8_t *)nullptr, (int *)nullptr, (int *)nullptr, dp);
         else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -244,7 +256,7 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
                 if (f->c0f) { (void)hipFree(f->c0f); f->c0f = nullptr; }
             }
             if (e == hipSuccess && f->xb16 && !f->exact16) {
-                hipLaunchKernelGGL(k_aux_margin, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb16, f->bn, nb, d, d + AUX16);
+                hipLaunchKernelGGL(k_aux_margin, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb16, f->bn, nb, dp, dp + AUX16);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
@@ -300,7 +312,7 @@ pf_status pf_flat_info(const pf_flat *f, size_t *nb, uint32_t *d) {
 pf_status pf_flat_reserve(pf_flat *f, size_t nq_max, uint32_t k_max) {
     if (!f || nq_max == 0 || k_max == 0) return fail(PF_ERR_INVALID_ARG, "bad argument");
     PF_GUARD(f->device);
-    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max, f->d).total);
+    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max, f->dp ? f->dp : f->d).total);
 }
 
 pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream) {
@@ -316,7 +328,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
     hipStream_t s = as_stream(stream);
-    const WsPlan w = plan_ws(f->nb, nq, k, f->d);
+    const uint32_t dp = f->dp ? f->dp : f->d;                         // the images' row length
+    const WsPlan w = plan_ws(f->nb, nq, k, dp);
     pf_status st = ensure_ws(f, w.total);
     if (st != PF_OK) return st;
     char *base = static_cast<char *>(f->ws);
@@ -336,8 +349,8 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     const bool b8 = b16 && f->xb8 && f->use8;                       // int8 tiles for the query tiles that turn out to be 8-bit too (flag bit 2, set by the kernel below)
     int8_t *q8 = reinterpret_cast<int8_t *>(base + w.off_q8);
     int *qsx = reinterpret_cast<int *>(base + w.off_qsx);
-    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, f->d,
-                                               false, b16 ? qbad : nullptr, 128u, b8 ? q8 : nullptr, f->d, (int8_t *)nullptr, (int *)nullptr, b8 ? qsx : nullptr);
+    if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, dp,
+                                               false, b16 ? qbad : nullptr, 128u, b8 ? q8 : nullptr, dp, (int8_t *)nullptr, (int *)nullptr, b8 ? qsx : nullptr, dp);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
     TileArgs t{};
     t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = f->exact16 ? 1u : 0u; t.bn_max = f->bn_max;
@@ -351,7 +364,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = b16 ? 2 : nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
-    const bool wide16 = b16 && f->d > 128;                                             // Geo16W
+    const bool wide16 = b16 && dp > 128;                                               // Geo16W
     const size_t TM = geo == 0 ? 32 : geo == 1 ? 64 : 128, TN = b16 ? (size_t)(wide16 ? Geo16W::TN : Geo16::TN) : geo == 2 ? 128 : 256;
     const size_t slots = b16 ? f->num_cus * (size_t)(wide16 ? 2 : B16_WG_PER_CU) : f->wg_slots;       // workgroups of the tile kernel resident at once
     t.n_qtiles = (uint32_t)((nq + TM - 1) / TM);
@@ -371,7 +384,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             const size_t n_groups = (nct + group - 1) / group;
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
-            switch (f->d) {
+            switch (dp) {
 #define PF_T16(DD) case DD: if (filter && DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128 && b8 && !t.i8_old) \
                                 hipLaunchKernelGGL((k_l2_tile16<true, DD, (DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128)>), grid16, dim3(256), 0, s, t, g32, n32); \
                             else if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \

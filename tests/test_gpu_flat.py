@@ -596,6 +596,42 @@ def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
         assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
 
 
+@pytest.mark.parametrize("d", [30, 100, 130, 200, 250])
+@pytest.mark.parametrize("law", ["u8", "int", "gauss", "mixed"])
+def test_padded_row_lengths_take_the_tile_path(d, law):
+    """[r4] row lengths that are not whole k-steps of the matrix instructions (any d up to 256): the operand images are padded with zeros and the
+    tile paths run -- int8 tiles on 8-bit data (d <= 128), bf16 tiles exact on integers / as a filter otherwise -- bit-identical to the
+    fp32-operand tiles and, on integer data, to the oracle.  Batches large enough for filtered chunks behind the bootstrap."""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(1000 * d + len(law))
+    nb, nq, k = 21000, 130, 50
+    if law == "u8":
+        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+    elif law == "int":
+        top = 128 if d > 128 else 256
+        xb, xq = rng.integers(-top, top + 1, (nb, d)), rng.integers(-top, top + 1, (nq, d))
+    elif law == "gauss":
+        xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
+    else:                                                            # an 8-bit base, queries that are not (a fraction somewhere): bf16 filter over an exact base
+        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d)) + (rng.random((nq, d)) < 0.01) * 0.5
+    xb, xq = xb.astype(np.float32), xq.astype(np.float32)
+    f = pf.FlatL2(xb, _dev())
+    q = torch.from_numpy(xq).to(_dev())
+    assert f.operands16() == (1 if law == "gauss" else 2)            # an image exists at this row length
+    assert f.operands8() == (law in ("u8", "mixed") and d <= 128)
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)                                          # fp32 operands
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    if f.operands8(-1) is not None and law == "u8" and d <= 128:
+        f.operands16(1); f.operands8(0)
+        D2, I2 = f.search(q, k)                                      # the same data through the bf16 tiles
+        assert (I2 == I0).all() and (D2.view(torch.int32) == D0.view(torch.int32)).all()
+    if law in ("u8", "int"):
+        Dr, Ir = oracle.flat_l2_search(xb, xq[:4], k)
+        assert (I1[:4].cpu().numpy() == Ir).all() and (D1[:4].cpu().numpy() == Dr).all()
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_bf16_filter_worst_case_rounding(d):
     """the bound the filter margin is priced on, met with equality: every coordinate is +-(1 + 2^-8) c -- exactly halfway between two
@@ -634,8 +670,9 @@ def test_exact16_path_refuses_inexact_data():
         f = pf.FlatL2(xb, dev)
         assert not f.exact16() and f.operands16() == 1                                                 # the image stays, as a filter's operand
     assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
-    for d in (100, 264, 272, 320):                                                                     # row lengths the bf16 tiles are not built for
+    for d in (264, 272, 320):                                                                          # row lengths the bf16 tiles are not built for (above 256)
         assert pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).operands16() == 0
+    assert pf.FlatL2(rng.integers(0, 256, (500, 100)).astype(np.float32), dev).operands16() == 2      # [r4] any row length up to 256: the image is padded with zeros
     assert pf.FlatL2(base, dev).operands16() == 2
 
 
