@@ -16,8 +16,8 @@ constexpr SwzEntry SWZ_TABLE[] = {
     PF_SWZ(11, 4, 1, 7, 2, 3,  3, 3, 0,  0, 0, 0)
     PF_SWZ(11, 5, 0, 6, 4, 1,  0, 0, 0,  0, 0, 0)
     PF_SWZ(11, 5, 1, 1, 1, 0,  4, 1, 0,  6, 4, 1)
-    PF_SWZ(12, 4, 0, 8, 1, 4,  0, 0, 0,  0, 0, 0)
-    PF_SWZ(12, 4, 1, 4, 1, 0,  8, 2, 3,  5, 4, 1)
+    PF_SWZ(12, 4, 0, 8, 2, 3,  0, 0, 0,  0, 0, 0)
+    PF_SWZ(12, 4, 1, 4, 1, 2,  5, 5, 0,  0, 0, 0)
     PF_SWZ(12, 5, 0, 7, 3, 2,  0, 0, 0,  0, 0, 0)
     PF_SWZ(12, 5, 1, 2, 1, 0,  4, 2, 0,  7, 3, 2)
     PF_SWZ(13, 4, 0, 0, 0, 0,  0, 0, 0,  0, 0, 0)

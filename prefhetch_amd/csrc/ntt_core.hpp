@@ -182,7 +182,13 @@ PF_HD void sub_from_const4(uint64_t K, const uint64_t (&m)[4], uint64_t (&d)[4])
 #ifndef PF_LOGR_LARGE
 #define PF_LOGR_LARGE 5        // log2(coefficients per thread) for N >= 4096
 #endif
-template <int LOGN_>
+#ifndef PF_LOGR_15
+#define PF_LOGR_15 6           // N = 32768: see the note inside Geo
+#endif
+constexpr int default_logr(int logn) { return logn >= 15 ? PF_LOGR_15 : (logn >= 12 ? PF_LOGR_LARGE : 4); }
+// LOGR_: log2(coefficients per thread).  The default is the geometry every kernel is built with; k_ctpt is also instantiated with 16 coefficients
+// per thread at N = 4096 / 8192 (pf_ntt_inst.hip) for launches that fill the device less than twice: twice the waves per polynomial.
+template <int LOGN_, int LOGR_ = default_logr(LOGN_)>
 struct Geo {
     static constexpr int LOGN = LOGN_;
     static constexpr int N = 1 << LOGN;
@@ -192,10 +198,7 @@ struct Geo {
     // forward 1.90 vs 1.95 ms, inverse 2.30 vs 1.99 ms, ct x pt 3.88 vs 3.67 ms, key switch 25.9 vs 26.6 ms per 256: no win.
     // The lone workgroup's phases (global load, passes, exchanges, store) do not overlap whatever its wave count, and the
     // last-pass layout then reads 256-byte runs per lane.  Kept selectable; the default stays 64.
-#ifndef PF_LOGR_15
-#define PF_LOGR_15 6
-#endif
-    static constexpr int LOGR = LOGN >= 15 ? PF_LOGR_15 : (LOGN >= 12 ? PF_LOGR_LARGE : 4);
+    static constexpr int LOGR = LOGR_;
     static constexpr int R = 1 << LOGR;
     static constexpr int T = N / R;                               // threads per workgroup
     static constexpr int P = (LOGN + LOGR - 1) / LOGR;            // passes per transform

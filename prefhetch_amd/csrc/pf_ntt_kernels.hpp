@@ -50,6 +50,13 @@ template <bool LAZY> struct ArithOf<ArithU64T<LAZY>> {
 // workgroup / 4 SIMDs, at least 2
 #define PF_WG_PER_CU(LOGN, A) ((160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8) > 3 ? 3 : (160 * 1024) / (Xchg<Geo<LOGN>, A>::LDS_ENTRIES * 8))
 #define PF_WAVES_PER_SIMD(LOGN, A) ((PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256) < 2 ? 2 : (PF_WG_PER_CU(LOGN, A) * Geo<LOGN>::T / 256))
+// ... for an explicit geometry class
+#ifndef PF_SMALL_GEO_WG
+#define PF_SMALL_GEO_WG 4
+#endif
+template <class G, class A> constexpr int wg_cap() { return G::LOGR < default_logr(G::LOGN) ? PF_SMALL_GEO_WG : 3; }
+template <class G, class A> constexpr int wg_per_cu() { return (160 * 1024) / (Xchg<G, A>::LDS_ENTRIES * 8) > wg_cap<G, A>() ? wg_cap<G, A>() : (160 * 1024) / (Xchg<G, A>::LDS_ENTRIES * 8); }
+template <class G, class A> constexpr int waves_per_simd() { return (wg_per_cu<G, A>() * G::T / 256) < 2 ? 2 : (wg_per_cu<G, A>() * G::T / 256); }
 
 #ifndef PF_KS_PERSIST
 #define PF_KS_PERSIST 0        // experiment, see k_ks_ntt: measured 24.1 ms per 256 key switches against 23.5 (the loop costs 124 B of scratch per thread)
@@ -125,10 +132,10 @@ template <int LOGN, class A0, int FLAGS>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 2) k_ctpt(NttArgs p) {
     using A = WholeXchg<A0>;
 #else
-template <int LOGN, class A, int FLAGS>
-__global__ void __launch_bounds__(Geo<LOGN>::T, PF_WAVES_PER_SIMD(LOGN, A)) k_ctpt(NttArgs p) {
+template <int LOGN, class A, int FLAGS, int LOGR = default_logr(LOGN)>
+__global__ void __launch_bounds__((Geo<LOGN, LOGR>::T), (waves_per_simd<Geo<LOGN, LOGR>, A>())) k_ctpt(NttArgs p) {
 #endif
-    using G = Geo<LOGN>;
+    using G = Geo<LOGN, LOGR>;
     __shared__ typename A::V lds[Xchg<G, A>::LDS_ENTRIES];
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const size_t m = (size_t)(j >> 1) * 8 + xcd;              // (ciphertext, limb) pair

@@ -43,6 +43,12 @@ def sim_lib_1024x32():
 
 
 @pytest.fixture(scope="session")
+def sim_lib_x16():
+    """The same core with 16 coefficients per thread at N = 4096 / 8192 (-DPF_LOGR_LARGE=4): the geometry k_ctpt takes for small launches."""
+    return _build_sim("libpf_sim_r4.so", ["-DPF_LOGR_LARGE=4"])
+
+
+@pytest.fixture(scope="session")
 def sim_lib():
     """Host execution of the device NTT core (tests/cpp/sim_ntt.cpp), built on demand."""
     return _build_sim("libpf_sim.so", [])

@@ -85,6 +85,34 @@ def test_selectable_geometry_1024x32_at_n32768(sim_lib_1024x32, q, arith):
     assert lib.pf_sim_range_violations() == 0
 
 
+@pytest.mark.parametrize("logn,q", [(12, 0xFFFFEE001), (12, 0xFFFFC4001), (13, 0x7FFFFFD8001), (13, 0xFFFFFF6C001)])
+def test_small_launch_geometry_16_per_thread(sim_lib_x16, logn, q):
+    """N = 4096 / 8192 at 16 coefficients per thread (what pf_ct_pt_mul launches when the batch fills the device less than twice): forward,
+    inverse and the fused product, exact-FP64 family, against the oracle.  N = 4096 is three full passes here -- the half-buffer exchange
+    drops one of two role-swapping index bits from the LDS position, and the slot swizzle must not fold the dropped bit onto its partner
+    (tools/lds_swizzle_search.py half_ok)."""
+    lib = sim_lib_x16
+    N = 1 << logn
+    o = oracle.Oracle(N, [q])
+    rng = np.random.default_rng(q & 0xFFFF)
+    for kind in (0, 1):
+        a, b = edge_poly(rng, N, q, kind), edge_poly(rng, N, q, 0)
+        dst = np.empty(N, dtype=np.uint64)
+        assert lib.pf_sim_run(logn, q, 0, 0, 0, _p(a), _p(a), _p(dst)) == 0
+        A = o.ntt_forward(a)
+        assert (dst == A).all()
+        assert lib.pf_sim_run(logn, q, 0, 1, 0, _p(A), _p(A), _p(dst)) == 0
+        assert (dst == a).all()
+        bn = o.ntt_forward(b)
+        for flags in (0, 1, 3, 5):
+            src = A if flags & 2 else a
+            acc0 = edge_poly(rng, N, q, 0)
+            dst = acc0.copy()
+            exp = o.ct_pt_mul(np.stack([src, src]).reshape(1, 2, 1, N), bn.reshape(1, 1, N), flags, acc=np.stack([acc0, acc0]).reshape(1, 2, 1, N)).reshape(2, N)[0]
+            assert lib.pf_sim_run(logn, q, 0, 2, flags, _p(src), _p(bn), _p(dst)) == 0
+            assert (dst == exp).all(), flags
+
+
 @pytest.mark.parametrize("qs", [oracle.BFV_DEFAULT[32768][:2] + oracle.BFV_DEFAULT[32768][-1:],
                                 [0x7FFFFFFF380001, 0x3FFFFFFF000001, 0xFFFFFFFFF70001]])          # mixed widths: a 54-bit modulus among 55/56-bit ones
 def test_two_pass_key_switch_core_on_host_simulator(sim_lib, qs):
