@@ -58,7 +58,17 @@ struct Walk8 {
 // group's first lane writes the key.  Wave-private: no barrier; LDS traffic of a wave executes in order.
 template <int D>
 __device__ __forceinline__ void walk8_flush(const TileArgs &p, Walk8Lds &L, const size_t q0, const uint32_t q_valid, const int lane, const uint32_t rc,
-                                            const uint32_t step0) {
+                                            const uint32_t step0, const uint32_t flush_no = 0) {
+#ifdef PF_FLAT_STAMPS      // (tools/flat_stamps.py) stamps 0 entry | 1 first decode done | 2 first rows + reservations requested | 3 exit; 6 / 7: records, list entries
+#define PF_F8STAMP(k, v) do { if (p.nb_count >= 400000 && blockIdx.x >= 256 && blockIdx.x < 256 + PF_FS_WGS && lane == 0 && flush_no < 8) \
+    pf_flat_flush_stamp_buf[(((blockIdx.x - 256) * 4 + (threadIdx.x >> 6)) * 8 + flush_no) * 8 + (k)] = (v); } while (0)
+    bool first_round = true;
+#else
+#define PF_F8STAMP(k, v) do { } while (0)
+    (void)flush_no;
+#endif
+    PF_F8STAMP(0, __builtin_readcyclecounter());
+    PF_F8STAMP(6, rc);
     constexpr uint32_t LU = D / 16;                                     // lanes of a group of 8 that hold 16 bytes of both rows
     constexpr int U = PF_W8_FLUSH_U;                                    // passes in flight (8 survivors each)
     uint32_t rb = 0, cur = 0, meta = 0;                                 // next batch of records; what is left of this lane's record
@@ -89,7 +99,10 @@ __device__ __forceinline__ void walk8_flush(const TileArgs &p, Walk8Lds &L, cons
             }
             ln += (uint32_t)__popcll(m);
         }
-        if (ln == 0) return;                                            // wave-uniform: nothing (left)
+        if (ln == 0) { PF_F8STAMP(3, __builtin_readcyclecounter()); return; }         // wave-uniform: nothing (left)
+#ifdef PF_FLAT_STAMPS
+        if (first_round) { PF_F8STAMP(1, __builtin_readcyclecounter()); PF_F8STAMP(7, ln); }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // ---- evaluation: group g = lane >> 3 takes survivor e0 + 8 u + g, its lane l = lane & 7 holds bytes 16 l .. 16 l + 15 of both rows
         const uint32_t g = (uint32_t)lane >> 3, l = (uint32_t)lane & 7u;
@@ -146,6 +159,9 @@ __device__ __forceinline__ void walk8_flush(const TileArgs &p, Walk8Lds &L, cons
             L.rcnt[r] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef PF_FLAT_STAMPS
+        if (first_round) { PF_F8STAMP(2, __builtin_readcyclecounter()); first_round = false; }
+#endif
 #if PF_W8_FLUSH_PIPE
         for (uint32_t e0 = 0; e0 < ln; e0 += 16 * U) {
             if (e0 + 8 * U < ln) request(SB, e0 + 8 * U);               // wave-uniform
@@ -305,10 +321,11 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         if (w1) L.ring[rc + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = make_uint2(w1, ((s - 1 - s0) << 7) | 64u | (uint32_t)lane);
         rc += n0 + (uint32_t)__popcll(m1);
     };
+    uint32_t nflush = 0;                                                // (flushes of this walk so far: only the stamped build looks at it)
     auto flush_if_full = [&]() {
         if (rc + 128 > Walk8Lds::RCAP) {                                // a step adds at most 128 records
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            walk8_flush<D>(p, L, q0, q_valid, lane, rc, s0);
+            walk8_flush<D>(p, L, q0, q_valid, lane, rc, s0, nflush++);
             rc = 0;
             load_afrag();                                               // (registers that need not live across the flush: fetched again)
             load_r0t();
@@ -358,7 +375,7 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
         if (w1) L.ring[rc + (uint32_t)__popcll(m1 & ((1ull << lane) - 1))] = make_uint2(w1, ((s1 - 1 - s0) << 7) | 64u | (uint32_t)lane);
         rc += (uint32_t)__popcll(m1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        walk8_flush<D>(p, L, q0, q_valid, lane, rc, s0);
+        walk8_flush<D>(p, L, q0, q_valid, lane, rc, s0, nflush);
         uint32_t sink = 0;
 #pragma unroll
         for (uint32_t a = 0; a < PF_W8_WARM; ++a) sink ^= warm[a];
