@@ -222,7 +222,8 @@ pf_status pf_ivfpq_get_list(const pf_ivfpq *idx, uint32_t list, uint8_t *codes_h
 pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *probe_host, size_t nq, uint32_t nprobe, float *D,
                                 int64_t *I, size_t capacity, uint64_t *list_sizes_host, pf_stream stream);
 
-/* 16-bit operands for the pre-filter (d a multiple of 16 up to 256, any number of queries).  pf_flat_create keeps a bf16 image of the
+/* 16-bit operands for the pre-filter (any row length, any number of queries; rows that are not whole k-steps of the matrix instruction are
+ * padded with zeros in the image).  pf_flat_create keeps a bf16 image of the
  * base (nearest-even) and checks on the device, value by value, whether it IS the base: every value an integer of magnitude
  * <= 256 (SIFT, the reference's dataset -- 8-bit values, /root/reference/include/common/client_server_utils.h:10-20 --
  * qualifies); query tiles are checked the same way at every search.
@@ -231,16 +232,20 @@ pf_status pf_ivfpq_search_lists(pf_ivfpq *idx, const float *xq, const int64_t *p
  *                     16-bit rows -- bit for bit the fp32 chain's number.
  *   inexact operands  the bf16 tiles run as a CONSERVATIVE FILTER (thresholds lowered by the bound on the operands' rounding,
  *                     2^-8 (|x|^2 + max |y|^2)); every survivor's distance is the k-ordered fp32 chain over the fp32 rows.
+ *   rows above 256    batches of more than 64 queries: bf16 tiles with both operands staged through LDS in k-slabs, always as a
+ *                     conservative filter (margin 2.1 x 2^-8 of |x|^2 + |y|^2, or the accumulations' rounding alone when every value
+ *                     on both sides is exactly representable); every candidate's distance is the fp32 chain's.
  * Either way (D, I) are what the fp32-operand loop returns, bit for bit; the caller never has to know.
  * mode 1 = on (default), 0 = fp32 operands always, -1 = query only.
- * *active_out (may be NULL): 2 = on with an exactly representable base, 1 = on as a filter over an inexact base, 0 = off. */
+ * *active_out (may be NULL): 2 = on with an exactly representable base (rows up to 256), 1 = on as a filter (an inexact base, or rows
+ * above 256), 0 = off. */
 pf_status pf_flat_exact16(pf_flat *idx, int mode, int *active_out);
 
 /* 8-bit integer operands for the pre-filter.  When EVERY value of the base is an integer in [0, 255] (SIFT: the reference's
- * dataset, /root/reference/include/common/client_server_utils.h:10-20) and d is a multiple of 32 up to 128, pf_flat_create also
- * keeps an int8 image (value - 128) and the filtered tiles of a query tile that is 8-bit as well (checked on the device at every
- * search) run v_mfma_i32_32x32x32_i8: exact integer accumulators, twice the depth per instruction of the bf16 form, half the
- * bytes through LDS.  Survivors are evaluated exactly as on the bf16 path: (D, I) are bit-identical to the fp32-operand loop's.
+ * dataset, /root/reference/include/common/client_server_utils.h:10-20) and d is at most 128, pf_flat_create also
+ * keeps int8 images (value - 128; row-major, and in the matrix instruction's fragment order) and the filtered chunks of a query tile that is
+ * 8-bit as well (checked on the device at every search) run v_mfma_i32_16x16x64_i8 straight from memory: exact integer accumulators,
+ * integer thresholds, no LDS staging.  Survivors are evaluated exactly (v_dot4_u32_u8): (D, I) are bit-identical to the fp32-operand loop's.
  * mode 1 on (default), 0 off (the bf16 tiles then run on the same data), -1 query; active_out: 1 when an image exists and is on. */
 pf_status pf_flat_operands8(pf_flat *idx, int mode, int *active_out);
 

@@ -284,7 +284,7 @@ class FlatL2:
     def operands16(self, mode=-1):
         """bf16 tiles of the batch pre-filter (pf_flat_exact16): mode 1 on (default), 0 fp32 operands always, -1 query.
         Returns 2 when on with an exactly representable base (the tiles evaluate the distance test itself), 1 when on as a
-        conservative filter over an inexact base (survivors re-evaluated by the fp32 chain), 0 when off."""
+        conservative filter (an inexact base, or rows longer than 256 values: survivors re-evaluated by the fp32 chain), 0 when off."""
         a = C.c_int()
         check(lib.pf_flat_exact16(self._h, int(mode), C.byref(a)), "pf_flat_exact16")
         return int(a.value)

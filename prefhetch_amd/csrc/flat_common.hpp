@@ -94,6 +94,7 @@ struct TileArgs {
     uint32_t i8_old;        // experiment knob (PF_FLAT_I8_OLD, read at index creation): the round-3 int8 walk (tile16_walk<.., I8>) instead of tile8_walk
     // the streamed int8 walk (flat_tile8.hpp): the base in fragment order, its columns' threshold halves, the queries' sum (x - 128)
     const int8_t *xb8f; const int *c0f; const int *qsx8;
+    uint32_t only_flagged;  // k_l2_tile beside the slab tiles (flat_wide16.hpp): only the query tiles whose word has bit 1 set
 };
 
 // Tile geometry: TM queries x TN base rows per workgroup of 256 threads (4 waves laid out WM x WN); a wave owns

@@ -269,6 +269,7 @@ __device__ __forceinline__ void l2_tile_f32(const TileArgs &p, char *smem, uint3
     const size_t q0 = (size_t)qt * TM;
     const size_t c0 = (size_t)ct * TN;                         // column inside the chunk
     if (c0 >= p.nb_count) return;
+    if (p.only_flagged && !(p.q_inexact[q0 / 128] & 2u)) return;   // (beside the slab tiles: this tile is theirs; workgroup-uniform)
     const size_t q_valid = p.nq - q0 < (size_t)TM ? p.nq - q0 : (size_t)TM;
     const size_t c_valid = p.nb_count - c0 < (size_t)TN ? p.nb_count - c0 : (size_t)TN;
     const int wm = (wave / GEO::WN) * (32 * MI), wn = (wave % GEO::WN) * (32 * NJ);

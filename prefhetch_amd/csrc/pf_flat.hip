@@ -37,6 +37,7 @@
 #include "flat_flush16.hpp"
 #include "flat_tile16.hpp"
 #include "flat_tile8.hpp"
+#include "flat_wide16.hpp"
 #include "flat_select.hpp"
 
 namespace pf {
@@ -99,6 +100,9 @@ struct pf_flat {
     bool use8 = true;             // pf_flat_operands8: the caller may switch the int8 tiles off (the bf16 tiles then run on the same data)
     int8_t *xb8f = nullptr;       // ... the same bytes in matrix-fragment order (flat_common.hpp: frag8_offset), what the filtered launches stream
     int *c0f = nullptr;           // ... and the columns' integer threshold halves (frag8_c0_index)
+    uint16_t *xbw = nullptr;      // rows longer than 256 values: the bf16 image [nb + 128][dpw] the slab tiles stream (flat_wide16.hpp); no exactness claim
+    uint32_t dpw = 0;             // ... its row length: d padded with zeros to whole 64-deep slabs
+    bool exactw = false;          // ... every value of the base is exactly representable in bf16 (8-bit data): the filter's margin is the accumulation's rounding only
     // workspace (grown outside graph capture)
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -113,6 +117,9 @@ struct pf_flat {
 
 namespace {
 
+#ifndef PF_WIDE_GROWTH_DIV
+#define PF_WIDE_GROWTH_DIV 5.0
+#endif
 #ifndef PF_BOOT_ROWS
 #define PF_BOOT_ROWS 8192
 #endif
@@ -183,6 +190,7 @@ pf_status pf_flat_destroy(pf_flat *f) {
         if (f->xb8) (void)hipFree(f->xb8);
         if (f->xb8f) (void)hipFree(f->xb8f);
         if (f->c0f) (void)hipFree(f->c0f);
+        if (f->xbw) (void)hipFree(f->xbw);
         if (f->bn) (void)hipFree(f->bn);
         if (f->ws) (void)hipFree(f->ws);
     }
@@ -242,7 +250,23 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
                                          f->xb8, dp + (uint32_t)AUX8, f->c0f ? f->xb8f : nullptr, f->c0f, (int *)nullptr, dp);
         else if (d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<32, PREP_MAX_D>), dim3((unsigned)((nb + 31) / 32)), dim3(64), 0, nullptr, f->xb, nb, d, f->bn, f->xb16, dp + AUX16, true, flag, 0u,
                                                      (int8_t *)nullptr, 0u, (int8_t *)nullptr, (int *)nullptr, (int *)nullptr, dp);
-        else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
+        else {
+            hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->bn);
+            // rows beyond the register-resident tiles: a bf16 image for the slab tiles (one tile of zero rows behind the end)
+            f->dpw = wide_row_length(d);
+            const size_t bytesw = (nb + 128) * (size_t)f->dpw * 2, threads = nb * (size_t)(f->dpw / 8);
+            if (getenv("PF_FLAT_NO_BF16") == nullptr && threads / 256 < (1ull << 31) &&
+                (hipMalloc((void **)&f->xbw, bytesw) != hipSuccess || hipMemset(f->xbw, 0, bytesw) != hipSuccess)) {
+                (void)hipGetLastError();                              // no room for the image: the fp32 path needs none
+                if (f->xbw) { (void)hipFree(f->xbw); f->xbw = nullptr; }
+            }
+            if (f->xbw && (hipMalloc((void **)&flag, 4) != hipSuccess || hipMemset(flag, 0, 4) != hipSuccess)) {
+                (void)hipGetLastError();
+                (void)hipFree(f->xbw); f->xbw = nullptr;
+                if (flag) { (void)hipFree(flag); flag = nullptr; }
+            }
+            if (f->xbw) hipLaunchKernelGGL(k_rows_bf16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr, f->xb, nb, d, f->xbw, f->dpw, flag, 0u);
+        }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (flag) {
@@ -250,6 +274,7 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
             if (e == hipSuccess) e = hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost);
             (void)hipFree(flag);
             f->exact16 = f->xb16 && !(inexact & 1u);       // inexact values: the image stays, as the operand of a conservative filter
+            f->exactw = f->xbw && !(inexact & 1u);
             if (f->xb8 && (inexact & 5u)) {                                                 // some value is not an integer in [0, 255]
                 (void)hipFree(f->xb8); f->xb8 = nullptr;
                 if (f->xb8f) { (void)hipFree(f->xb8f); f->xb8f = nullptr; }
@@ -260,6 +285,13 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
+        }
+        if (e == hipSuccess && f->xbw) {             // a norm that is not finite rules the slab tiles' filter out
+            std::vector<float> norms(nb);
+            e = hipMemcpy(norms.data(), f->bn, nb * 4, hipMemcpyDeviceToHost);
+            bool finite = true;
+            for (float v : norms) { finite = finite && std::isfinite(v); if (v > f->bn_max) f->bn_max = v; }
+            if (!finite) { (void)hipFree(f->xbw); f->xbw = nullptr; f->exactw = false; }
         }
         if (e == hipSuccess && f->xb16) {            // largest row norm; a norm that is not finite rules the filter out
             std::vector<float> norms(nb);
@@ -291,7 +323,7 @@ pf_status pf_flat_create(pf_flat **out, int device, const float *xb, size_t nb, 
 pf_status pf_flat_exact16(pf_flat *f, int mode, int *active) {
     if (!f || mode < -1 || mode > 1) return fail(PF_ERR_INVALID_ARG, "pf_flat_exact16: index, and mode -1 (query), 0 (off) or 1 (on where exact)");
     if (mode >= 0) f->use16 = mode == 1;
-    if (active) *active = f->xb16 && f->use16 ? (f->exact16 ? 2 : 1) : 0;
+    if (active) *active = f->xb16 && f->use16 ? (f->exact16 ? 2 : 1) : (f->xbw && f->use16 ? 1 : 0);
     return PF_OK;
 }
 
@@ -312,7 +344,7 @@ pf_status pf_flat_info(const pf_flat *f, size_t *nb, uint32_t *d) {
 pf_status pf_flat_reserve(pf_flat *f, size_t nq_max, uint32_t k_max) {
     if (!f || nq_max == 0 || k_max == 0) return fail(PF_ERR_INVALID_ARG, "bad argument");
     PF_GUARD(f->device);
-    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max, f->dp ? f->dp : f->d).total);
+    return ensure_ws(f, plan_ws(f->nb, nq_max, k_max, f->dp ? f->dp : (f->xbw ? f->dpw : f->d)).total);
 }
 
 pf_status pf_flat_search(pf_flat *f, const float *xq, size_t nq, uint32_t k, float *D, int64_t *I, pf_stream stream) {
@@ -328,7 +360,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     if (nq > (1u << 20)) return fail(PF_ERR_INVALID_ARG, "nq too large for one call (at most 2^20 queries)");
     PF_GUARD(f->device);
     hipStream_t s = as_stream(stream);
-    const uint32_t dp = f->dp ? f->dp : f->d;                         // the images' row length
+    const uint32_t dp = f->dp ? f->dp : (f->xbw ? f->dpw : f->d);     // the images' row length
     const WsPlan w = plan_ws(f->nb, nq, k, dp);
     pf_status st = ensure_ws(f, w.total);
     if (st != PF_OK) return st;
@@ -345,22 +377,25 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     const bool b16 = f->xb16 && f->use16 && nq >= f->b16_min_nq;
     uint16_t *q16 = reinterpret_cast<uint16_t *>(base + w.off_q16);
     uint32_t *qbad = reinterpret_cast<uint32_t *>(base + w.off_qbad);
-    if (b16) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
+    const bool wide = f->xbw && f->use16 && nq > 64;                // rows longer than 256 values, batches: the slab tiles (flat_wide16.hpp)
+    if (b16 || wide) PF_HIP(hipMemsetAsync(qbad, 0, ((nq + 127) / 128) * 4, s));
     const bool b8 = b16 && f->xb8 && f->use8;                       // int8 tiles for the query tiles that turn out to be 8-bit too (flag bit 2, set by the kernel below)
     int8_t *q8 = reinterpret_cast<int8_t *>(base + w.off_q8);
     int *qsx = reinterpret_cast<int *>(base + w.off_qsx);
     if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, dp,
                                                false, b16 ? qbad : nullptr, 128u, b8 ? q8 : nullptr, dp, (int8_t *)nullptr, (int *)nullptr, b8 ? qsx : nullptr, dp);
     else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
+    // rows longer than 256 values, batches: the filtered chunks run the slab tiles over bf16 images (flat_wide16.hpp); the queries' image is built here
+    if (wide) hipLaunchKernelGGL(k_rows_bf16, dim3((unsigned)((nq * (size_t)(f->dpw / 8) + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, q16, f->dpw, qbad, 128u);
     TileArgs t{};
-    t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = f->exact16 ? 1u : 0u; t.bn_max = f->bn_max;
+    t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = (wide ? f->exactw : f->exact16) ? 1u : 0u; t.bn_max = f->bn_max;
     t.xq8 = b8 ? q8 : nullptr; t.xb8 = b8 ? f->xb8 : nullptr; t.i8_old = (f->i8_old || !f->xb8f) ? 1u : 0u;
     t.xb8f = f->xb8f; t.c0f = f->c0f; t.qsx8 = qsx;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
     SelArgs a{};
     a.slab = slab; a.slab_ld = (uint32_t)w.slab_ld; a.state = state; a.state_cnt = scnt; a.tau = tau; a.cand_cnt = ccnt; a.cand = cand;
-    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I; a.packed = packed; a.q_flags = b16 ? qbad : nullptr; a.bn_max = f->bn_max; a.base_exact = f->exact16 ? 1u : 0u;
+    a.cap = (uint32_t)w.cap; a.xq = xq; a.xb = f->xb; a.qn = qn; a.bn = f->bn; a.d = f->d; a.k = k; a.D = D; a.I = I; a.packed = packed; a.q_flags = b16 || wide ? qbad : nullptr; a.bn_max = f->bn_max; a.base_exact = t.base_exact;
     // tile geometry by batch size: 128-row query tiles for batches, 32 / 64-row tiles when a 128-row tile would be
     // mostly padding (the scan of the base is then HBM-bound instead of MFMA-bound)
     const int geo = b16 ? 2 : nq <= 32 ? 0 : nq <= 64 ? 1 : 2;
@@ -401,6 +436,18 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             return;
         }
         const dim3 grid((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles));
+        if (wide && filter) {
+            const float acc_term = (float)f->d * 0x1p-21f;
+            hipLaunchKernelGGL(k_l2_wide16, grid, dim3(256), 0, s, t, (const uint16_t *)q16, (const uint16_t *)f->xbw, f->dpw, WIDE_MARGIN + acc_term, acc_term);
+            const uint32_t per_q = (uint32_t)((w.cap + 255) / 256);
+            hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nq * per_q)), dim3(256), 0, s, t, per_q);
+            // the query tiles the filter does not separate for (their word's bit 1): fp32 tiles, the same launch geometry, every other workgroup leaves at once
+            TileArgs tf = t;
+            tf.only_flagged = 1u;
+            if (f->d % TK == 0) hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, true, false>), grid, dim3(256), 0, s, tf);
+            else hipLaunchKernelGGL((k_l2_tile<true, GeoBatch, false, false>), grid, dim3(256), 0, s, tf);
+            return;
+        }
         const bool fast = f->d % TK == 0;
 #define PF_TILE(FILTER, GEO, AGG) do { if (fast) hipLaunchKernelGGL((k_l2_tile<FILTER, GEO, true, AGG>), grid, dim3(256), 0, s, t); \
                                        else hipLaunchKernelGGL((k_l2_tile<FILTER, GEO, false, AGG>), grid, dim3(256), 0, s, t); } while (0)
@@ -440,7 +487,9 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     int n_chunks = 0, chunk_no = 0;
     if (geo == 2 && f->nb > boot) {
         // (the streamed int8 walk pays more per launch and less per survivor than the LDS-tiled walks: 2.3 makes 1M rows three chunks of ratio 5 -- 0.354 -> 0.345 ms)
-        const double div = growth_div > 0.0 ? growth_div : (b8 && !t.i8_old ? 2.3 : 3.0), g_max = 1.0 + (double)w.cap / (div * (double)k), span = (double)f->nb / (double)boot;
+        // (the slab tiles of rows beyond 256 values pay for every survivor with a row of the fp32 matrix re-read: more, smaller steps carry fewer
+        // survivors in all -- n (r - 1) falls towards ln(nb / boot) -- and a launch is cheap next to their tiles)
+        const double div = growth_div > 0.0 ? growth_div : (b8 && !t.i8_old ? 2.3 : wide ? PF_WIDE_GROWTH_DIV : 3.0), g_max = 1.0 + (double)w.cap / (div * (double)k), span = (double)f->nb / (double)boot;
         n_chunks = (int)ceil(log(span) / log(g_max) - 1e-9);
         if (n_chunks < 1) n_chunks = 1;
         ratio = pow(span, 1.0 / n_chunks);

@@ -632,6 +632,68 @@ def test_padded_row_lengths_take_the_tile_path(d, law):
         assert (I1[:4].cpu().numpy() == Ir).all() and (D1[:4].cpu().numpy() == Dr).all()
 
 
+@pytest.mark.parametrize("d", [257, 260, 384, 500, 1024])
+@pytest.mark.parametrize("law", ["u8", "gauss", "mixed_norms"])
+def test_rows_longer_than_256_take_the_slab_tiles(d, law):
+    """[r4] rows longer than 256 values: the filtered chunks run bf16 tiles with both operands staged in k-slabs (a conservative filter) and every
+    candidate's distance comes from the fp32 chain afterwards -- (D, I) bit-identical to the fp32-operand tiles and, on integer data, to the oracle.
+    Batches above 64 queries, a base long enough for filtered chunks behind the bootstrap, a ragged last query tile and column tile."""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(7 * d + len(law))
+    nb, nq, k = 20011, 150, 40
+    if law == "u8":
+        xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
+    elif law == "gauss":
+        xb, xq = rng.standard_normal((nb, d)), rng.standard_normal((nq, d))
+    else:                                                            # rows of very different norms, queries close to some of them
+        xb = rng.standard_normal((nb, d)) * rng.choice([0.01, 1.0, 30.0], (nb, 1))
+        xq = xb[rng.integers(8192, nb, nq)] + 0.05 * rng.standard_normal((nq, d))
+    xb, xq = xb.astype(np.float32), xq.astype(np.float32)
+    f = pf.FlatL2(xb, _dev())
+    q = torch.from_numpy(xq).to(_dev())
+    assert f.operands16() == 1                                       # the slab image exists; no exactness claim at these lengths
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)                                          # fp32 operands
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    if law == "u8":
+        Dr, Ir = oracle.flat_l2_search(xb, xq[:3], k)
+        if d * 255 * 255 < 2 ** 24:                                  # every partial sum an integer fp32 holds: the decomposition is exact
+            assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
+        else:                                                        # beyond, |x|^2 + |y|^2 - 2 x.y rounds where the oracle's double sum does not
+            # (the fp32 chain of 1024 products of magnitude 2^16 drifts by 3e-5 of the distance: the decomposition's rounding, the same with fp32 operands)
+            np.testing.assert_allclose(D1[:3].cpu().numpy(), Dr, rtol=RTOL if d <= 512 else 1e-4)
+
+
+def test_slab_tiles_worst_case_rounding_and_nonfinite_queries():
+    """d = 512: every coordinate +-(1 + 2^-8) c (halfway between two bf16 values: every product loses the full rounding), queries copies of base rows
+    behind the bootstrap chunk -- the margin of the slab tiles' filter met with equality; and a batch with NaN / Inf / 1e30 inside some queries:
+    both equal the fp32-operand tiles bit for bit"""
+    import prefhetch_amd as pf
+    rng = np.random.default_rng(29)
+    d, nb, nq, k = 512, 24000, 140, 10
+    mag = np.float32(3.0) * np.float32(1.0 + 2.0 ** -8)
+    xb = (rng.integers(0, 2, (nb, d)) * 2 - 1).astype(np.float32) * mag
+    xq = xb[rng.integers(8192, nb, nq)].copy()
+    flip = rng.integers(0, d, (nq, 3))
+    for i in range(nq):
+        xq[i, flip[i]] *= -1                                          # three coordinates away from its row
+    f = pf.FlatL2(xb, _dev())
+    q = torch.from_numpy(xq).to(_dev())
+    D1, I1 = f.search(q, k)
+    f.operands16(0)
+    D0, I0 = f.search(q, k)
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+    xq2 = rng.standard_normal((nq, d)).astype(np.float32)
+    xq2[3, 7] = np.nan; xq2[70, 0] = np.inf; xq2[139, 500] = 1e30; xq2[5, 100] = -np.inf
+    g = pf.FlatL2(rng.standard_normal((nb, d)).astype(np.float32), _dev())
+    q2 = torch.from_numpy(xq2).to(_dev())
+    D1, I1 = g.search(q2, k)
+    g.operands16(0)
+    D0, I0 = g.search(q2, k)
+    assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all()
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_bf16_filter_worst_case_rounding(d):
     """the bound the filter margin is priced on, met with equality: every coordinate is +-(1 + 2^-8) c -- exactly halfway between two
@@ -670,8 +732,8 @@ def test_exact16_path_refuses_inexact_data():
         f = pf.FlatL2(xb, dev)
         assert not f.exact16() and f.operands16() == 1                                                 # the image stays, as a filter's operand
     assert not pf.FlatL2(rng.standard_normal((5000, 128)).astype(np.float32), dev).exact16()
-    for d in (264, 272, 320):                                                                          # row lengths the bf16 tiles are not built for (above 256)
-        assert pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).operands16() == 0
+    for d in (264, 272, 320):                                                                          # [r4] above 256: the slab tiles' image, a filter's operand whatever the data
+        assert pf.FlatL2(rng.integers(0, 256, (500, d)).astype(np.float32), dev).operands16() == 1
     assert pf.FlatL2(rng.integers(0, 256, (500, 100)).astype(np.float32), dev).operands16() == 2      # [r4] any row length up to 256: the image is padded with zeros
     assert pf.FlatL2(base, dev).operands16() == 2
 

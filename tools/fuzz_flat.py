@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of FlatL2.search: bf16 tiles vs fp32 operands (bit for bit), and the oracle on integer-valued data.
-usage: tools/fuzz_flat.py [iterations] [seed] [i8]"""
+usage: tools/fuzz_flat.py [iterations] [seed] [i8 | wide]   (wide: row lengths above 256 -- the slab tiles -- including odd ones; no oracle
+comparison there on integer data beyond 2^24, where the decomposition itself rounds)"""
 import os, sys
 import numpy as np
 import torch
@@ -17,11 +18,18 @@ for it in range(iters):
     only8 = len(sys.argv) > 3 and sys.argv[3] == "i8"          # third argument "i8": 8-bit data at the int8 tiles' row lengths only
     if only8:
         d = int(rng.choice([32, 64, 96, 128]))
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    if wide:
+        d = int(rng.choice([257, 260, 300, 320, 384, 511, 512, 640, 777, 1024, 1536]))
     nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 60000), rng.integers(60000, 400000)]))
+    if wide:
+        nb = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 40000), rng.integers(40000, 120000)]))
     nq = int(rng.choice([rng.integers(1, 70), rng.integers(70, 300), rng.integers(300, 700)]))
     k = int(min(rng.choice([1, 7, 64, 200, 256, 257, 1024]), 1024))
     law = str(rng.choice(["int", "ties", "dups", "part8"])) if len(sys.argv) > 3 and sys.argv[3] == "i8" else str(rng.choice(["int", "ties", "gauss", "mixed", "dups", "neg"]))
     top = 256 if d <= 128 else 128       # (|x|^2 + |y|^2 < 2^24: the oracle's exact distance is what the fp32 formula returns)
+    if wide:
+        top = 64 if d <= 512 else 32
     if law == "int":
         xb, xq = rng.integers(0, top, (nb, d)), rng.integers(0, top, (nq, d))
     elif law == "ties":
