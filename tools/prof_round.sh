@@ -29,8 +29,11 @@ bash tools/flat_timeline.sh 1024 > $O/${tag}_flat_timeline.txt 2>&1
 PF_RK_LAW=gauss bash tools/flat_timeline.sh 1024 > $O/${tag}_flat_timeline_gaussian.txt 2>&1
 fi
 if [ "$part" != 1 ]; then
-python3 tools/time_flat_d.py > $O/${tag}_flat_row_lengths.txt 2>&1
+python3 tools/time_flat_d.py 30 32 100 96 128 200 192 256 > $O/${tag}_flat_row_lengths.txt 2>&1
 python3 tools/time_ctpt_small.py > $O/${tag}_ctpt_small_launches.txt 2>&1
+python3 tools/time_flat_wide.py 384 512 1024 > $O/${tag}_flat_wide_rows.txt 2>&1
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_wide -- python3 $R/tools/run_flat_wide.py 512 gauss > $O/prof_${tag}_wide.log 2>&1
+cd $R && python3 tools/prof_summary.py $(find $O/prof_${tag}_wide -name "*kernel_stats.csv" | head -1) $O/${tag}_flat_wide_512_kernel_stats.txt
 python3 tools/time_flat_gauss.py > $O/${tag}_flat_gaussian.txt 2>&1
 python3 tools/sweep_shapes.py > $O/${tag}_shapes_sweep.json 2> $O/${tag}_shapes_sweep.err
 python3 tools/sweep_flat.py > $O/${tag}_flat_sweep.json 2> $O/${tag}_flat_sweep.err
