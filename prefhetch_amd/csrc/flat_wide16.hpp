@@ -49,10 +49,41 @@ __global__ void __launch_bounds__(256) k_rows_bf16(const float *__restrict__ x, 
         w[j] = h[0] | (h[1] << 16);
     }
     *reinterpret_cast<u32x4 *>(out + r * (size_t)dpw + k0) = w;
-    if (bad && inexact) {                                       // (one word may take every thread of the launch: look before asking for the atomic)
-        uint32_t *w = &inexact[rows_per_flag ? r / rows_per_flag : 0];
-        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) atomicOr(w, 1u);
+    if (inexact) {
+        // one word may take every thread of the launch (725 ms for a 1M x 512 base when each asked for its own atomic): a wave settles its words
+        // one at a time -- a leader looks first and asks for the atomic only when the bit is still clear
+        uint32_t idx = bad ? (uint32_t)(rows_per_flag ? r / rows_per_flag : 0) : 0xFFFFFFFFu;
+        for (;;) {
+            const uint64_t m = __ballot(idx != 0xFFFFFFFFu);
+            if (m == 0) break;                                  // wave-uniform
+            const int leader = __ffsll((long long)m) - 1;
+            const uint32_t lidx = (uint32_t)__shfl((int)idx, leader);
+            if ((int)(threadIdx.x & 63) == leader && !(*reinterpret_cast<volatile uint32_t *>(inexact + lidx) & 1u)) atomicOr(&inexact[lidx], 1u);
+            if (idx == lidx) idx = 0xFFFFFFFFu;
+        }
     }
+}
+
+// row norms (the fp32 fma chain in index order: k_row_norms' number) of a FEW long rows -- the queries of a search: one wave per row.  The chain is
+// serial, but a thread per row (k_row_norms) also reads its row alone, 4 bytes at a time: 66 us for 1024 rows of 512 values.  Here the wave copies
+// the row into LDS (coalesced, segments of 2048 values) and its first lane chains it from there.
+__global__ void __launch_bounds__(256) k_row_norms_wave(const float *__restrict__ x, size_t n, uint32_t d, float *__restrict__ out) {
+    constexpr uint32_t SEG = 2048;
+    __shared__ float seg[4][SEG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t r = (size_t)blockIdx.x * 4 + wave;
+    if (r >= n) return;                                         // wave-uniform
+    const float *row = x + r * (size_t)d;
+    float acc = 0.f;
+    for (uint32_t k0 = 0; k0 < d; k0 += SEG) {
+        const uint32_t kn = d - k0 < SEG ? d - k0 : SEG;
+        for (uint32_t k = lane; k < kn; k += 64) seg[wave][k] = row[k0 + k];
+        wave_sync();
+        if (lane == 0)
+            for (uint32_t k = 0; k < kn; ++k) acc = fmaf(seg[wave][k], seg[wave][k], acc);
+        wave_sync();
+    }
+    if (lane == 0) out[r] = acc;
 }
 
 // 128 rows x one slab: thread t moves the 16-byte chunks c = t + 256 it (row c / 8, chunk c % 8); rows past the end re-read the last valid row

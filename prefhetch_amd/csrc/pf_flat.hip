@@ -384,7 +384,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     int *qsx = reinterpret_cast<int *>(base + w.off_qsx);
     if (f->d <= PREP_MAX_D) hipLaunchKernelGGL((k_rows_prep<4, PREP_MAX_D>), dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, s, xq, nq, f->d, qn, b16 ? q16 : nullptr, dp,
                                                false, b16 ? qbad : nullptr, 128u, b8 ? q8 : nullptr, dp, (int8_t *)nullptr, (int *)nullptr, b8 ? qsx : nullptr, dp);
-    else hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, qn);
+    else hipLaunchKernelGGL(k_row_norms_wave, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, xq, nq, f->d, qn);
     // rows longer than 256 values, batches: the filtered chunks run the slab tiles over bf16 images (flat_wide16.hpp); the queries' image is built here
     if (wide) hipLaunchKernelGGL(k_rows_bf16, dim3((unsigned)((nq * (size_t)(f->dpw / 8) + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, q16, f->dpw, qbad, 128u);
     TileArgs t{};
