@@ -239,13 +239,16 @@ def config2_block(pf, dev):
     out = torch.empty_like(ct)
     for _ in range(10):
         ctx.ct_pt_mul(ct, pt, out=out)
-    ms = _timed(lambda: ctx.ct_pt_mul(ct, pt, out=out), 200)
+    # a 28 us launch: five batches of 50 back-to-back launches, the median batch reported (the batches differ by 10 % with the clock state the
+    # blocks before this one leave behind; the best batch is in best_batch_ms)
+    batches = sorted(_timed(lambda: ctx.ct_pt_mul(ct, pt, out=out), 50) for _ in range(5))
+    ms = batches[2]
     alg = 40 * len(qs) * N * B
     exp = oracle.Oracle(N, qs).ct_pt_mul(pf.to_host_u64(ct[:2]), pf.to_host_u64(pt[:2]))
-    return {"workload": "N=4096, 2 limbs, batch 256 fused ct x pt", "ct_x_pt_ms": ms, "queries_per_s": B / (ms * 1e-3),
+    return {"workload": "N=4096, 2 limbs, batch 256 fused ct x pt", "ct_x_pt_ms": ms, "best_batch_ms": batches[0], "queries_per_s": B / (ms * 1e-3),
             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
             "first_2_bit_exact_vs_oracle": bool((pf.to_host_u64(out[:2]) == exp).all()),
-            "note": "200 back-to-back launches after 10 untimed ones; one launch of 1024 workgroups is a single round of resident ones (16 coefficients per thread, "
+            "note": "median of 5 batches of 50 back-to-back launches after 10 untimed ones; one launch of 1024 workgroups is a single round of resident ones (16 coefficients per thread, "
                     "picked at run time for launches this small): latency-bound shape"}
 
 
@@ -265,9 +268,17 @@ def config5_block(pf, dev):
     ms_ctpt = _timed(lambda: ctx.ct_pt_mul(ct, pt, out=out), 5)
     h_ct, h_pt = pf.to_host_u64(ct[rows]), pf.to_host_u64(pt[rows])
     ok_ctpt = bool((pf.to_host_u64(out[rows]) == o.ct_pt_mul(h_ct, h_pt)).all())
-    ms_fwd = _timed(lambda: ctx.ntt_forward(ct, out=out), 5)
+    ms_fwd_oop = _timed(lambda: ctx.ntt_forward(ct, out=out), 5)      # out of place: one kernel per polynomial (its result is what is verified below)
     ok_fwd = bool((pf.to_host_u64(out[rows]) == o.ntt_forward(h_ct)).all())
+    # SEAL transforms in place (transform_to_ntt_inplace): that form runs as two Infinity-Cache-sized passes at this ring degree.
+    # Timed on the buffer below AFTER its check (the values wander; only the duration is used), as the inverse always was.
+    ms_fwd = _timed(lambda: ctx.ntt_forward(out, out=out), 5)
     ms_inv = _timed(lambda: ctx.ntt_inverse(out, out=out), 5)          # (timed in place on its own output: only the duration is used)
+    # the in-place forward transform against the oracle too (the two-pass form), and the inverse: the inverse of the forward transform of the rows must be the rows
+    chk2 = ct[rows].contiguous()
+    ctx.ntt_forward(chk2, out=chk2)
+    ok_fwd = ok_fwd and bool((pf.to_host_u64(chk2) == o.ntt_forward(h_ct)).all())
+    del chk2
     # the inverse transform against the oracle as well: the inverse of the forward transform of the rows must be the rows
     chk = ctx.ntt_forward(ct[rows].contiguous())
     ctx.ntt_inverse(chk, out=chk)
@@ -290,12 +301,13 @@ def config5_block(pf, dev):
     ks_bytes = B * (D * N * 8 + 2 * 2 * D * N * 8) + D * 2 * K * N * 8
     return {"workload": "N=32768, 15 data primes + special prime, batch 256",
             "forward_ntt_ms": ms_fwd, "forward_frac": 16 * N * n_polys / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "forward_note": "in place, as SEAL transforms (two Infinity-Cache-sized passes: k_nsA, k_nsB); out of place (one kernel per polynomial) %.3f ms" % ms_fwd_oop,
             "inverse_ntt_ms": ms_inv, "inverse_frac": 16 * N * n_polys / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "ct_x_pt_ms": ms_ctpt, "ct_x_pt_frac": 40 * D * N * B / (ms_ctpt * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "key_switch_ms_per_256": ms_ks, "key_switch_us_per_polynomial": 1e3 * ms_ks / B,
             "key_switch_digit_transforms": B * D * K, "key_switch_ns_per_digit_transform": 1e6 * ms_ks / (B * D * K),
             "key_switch_algorithmic_bytes": ks_bytes, "key_switch_frac_of_hbm_peak": ks_bytes / (ms_ks * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "key_switch_bound": "valu (61 440 transforms of 32768 points in 64-bit modular arithmetic per batch; PMC: profiles/r03_z_pmc_keyswitch.txt)",
+            "key_switch_bound": "valu (61 440 transforms of 32768 points in 64-bit modular arithmetic per batch; PMC: profiles/r04_pmc_keyswitch.txt)",
             # what the counters saw (2 x FETCH_SIZE + WRITE_SIZE of k_ksA / k_ksB / k_ksC, profiles/r03_z_pmc_keyswitch.txt: 5.67 GB per round of
             # 32 ciphertexts): the intermediate digit transforms cross memory once each way -- not collected in this run
             "key_switch_counter_bytes_per_256": 45.4e9, "key_switch_counter_over_algorithmic": 45.4e9 / ks_bytes,
