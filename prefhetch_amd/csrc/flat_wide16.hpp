@@ -7,7 +7,7 @@
 // global -> registers -> LDS (row-major, 16-byte chunks, no transposition: the matrix instruction's fragment IS 16 consecutive bytes of a row), two
 // slabs in flight, one barrier per slab, v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The images are the nearest bf16 of every value, so the
 // accumulator is x.y up to |x~.y~ - x.y| <= (2^-9 + 2^-19)(|x|^2 + |y|^2) plus the accumulation's own rounding; the epilogue (l2_tile_epilogue, the
-// fp32 tiles' own) tests  (|x|^2 + |y|^2)(1 - m) - 2 acc <= tau  with m = 2.1 x 2^-8 + d x 2^-21 (d x 2^-21 alone when every value of the base and of the
+// fp32 tiles' own) tests  (|x|^2 + |y|^2)(1 - m) - 2 acc <= tau  with m = 2.1 x 2^-8 + d x 2^-20 (d x 2^-20 alone when every value of the base and of the
 // query tile is exactly representable -- 8-bit data: only the two accumulations' rounding is left), which never drops a row the fp32 chain would keep,
 // and appends (approximate distance, id) keys to the query's candidate list.  k_wide_fixup then recomputes the distance of every entry of the
 // lists with the same k-ordered fmaf chain and final expression as every other path (one lane per entry) and rewrites the key in place: what the

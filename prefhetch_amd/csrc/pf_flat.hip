@@ -437,7 +437,9 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
         }
         const dim3 grid((unsigned)(((nct + 7) / 8) * 8 * t.n_qtiles));
         if (wide && filter) {
-            const float acc_term = (float)f->d * 0x1p-21f;
+            // the two accumulations' rounding, dist-level and relative to |x|^2 + |y|^2: the fp32 chain's d roundings of at most half an ulp of a
+            // partial sum <= (|x|^2 + |y|^2) / 2, the matrix pipe's d of at most a whole one (should it truncate), doubled by the -2: 3 d 2^-24; taken as d 2^-20
+            const float acc_term = (float)f->d * 0x1p-20f;
             hipLaunchKernelGGL(k_l2_wide16, grid, dim3(256), 0, s, t, (const uint16_t *)q16, (const uint16_t *)f->xbw, f->dpw, WIDE_MARGIN + acc_term, acc_term);
             const uint32_t per_q = (uint32_t)((w.cap + 255) / 256);
             hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nq * per_q)), dim3(256), 0, s, t, per_q);
