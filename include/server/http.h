@@ -40,12 +40,16 @@ class HttpListener {
     // max_requests > 0, that many requests have been answered.  Returns the number of requests answered.
     size_t serve(size_t max_requests = 0);
     void stop();
+    // A request that is not complete this long after its first byte is answered 408 and its connection closed (default 10 s) -- a deadline per
+    // request, not an idle timer between bytes.  Call before serve().
+    void set_request_timeout_ms(int ms) { m_RequestTimeoutMs = ms; }
 
   private:
     HttpHandler m_Handler;
     int m_Fd = -1;
     uint16_t m_Port = 0;
     size_t m_MaxBody;
+    int m_RequestTimeoutMs = 10000;
     std::atomic<bool> m_Stop{false};
 };
 

@@ -68,6 +68,7 @@ class Server {
     // ||q||^2 and the row norms to obtain the squared distances preciseSearch returns.
     static constexpr uint32_t ENC_RING_DEGREE = 8192, ENC_LIMBS = 4;
     static constexpr uint64_t ENC_MODULI[ENC_LIMBS] = {0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001};
+    static constexpr uint64_t ENC_SPECIAL_PRIME = 0xFFFFFEBC001;     // the key modulus behind them (SEAL BFVDefault(8192)'s fifth prime): key-switching keys carry a limb of it
     static constexpr uint32_t ENC_ROWS_PER_POLY = ENC_RING_DEGREE / PRECISE_VECTOR_DIMENSIONS;
     static constexpr uint32_t ENC_POLYS_PER_QUERY = (COARSE_PROBE + ENC_ROWS_PER_POLY - 1) / ENC_ROWS_PER_POLY;
     void preciseSearchEncrypted(const uint64_t *query_ct_device /* [NQUERY][2][4][8192] */,

@@ -167,13 +167,16 @@ Parse try_parse(std::string &buf, Message &m, size_t max_body, bool &head_done) 
 // One thread, many connections: the listening socket and every open client socket sit in ONE poll set, bytes are taken off a
 // socket only when poll says they are there (never a blocking recv), and a request is handled -- one at a time, like the
 // reference, which never calls setThreadNum -- as soon as all of it is buffered.  A client that stalls in the middle of a request is
-// answered 408 and closed after REQUEST_TIMEOUT_MS, an idle keep-alive connection is closed after IDLE_TIMEOUT_MS; neither keeps
+// answered 408 and closed once its request is older than the request timeout (10 s unless set_request_timeout_ms says otherwise), an idle keep-alive connection is closed after IDLE_TIMEOUT_MS; neither keeps
 // any other client waiting, and stop() is seen within one poll interval whatever the clients do.
 size_t HttpListener::serve(size_t max_requests) {
     using Clock = std::chrono::steady_clock;
-    constexpr int POLL_MS = 100, REQUEST_TIMEOUT_MS = 10000, IDLE_TIMEOUT_MS = 30000, SEND_TIMEOUT_S = 10;
+    constexpr int POLL_MS = 100, IDLE_TIMEOUT_MS = 30000, SEND_TIMEOUT_S = 10;
     constexpr size_t MAX_CONNECTIONS = 256;
-    struct Conn { int fd; std::string buf; Clock::time_point last; bool continued = false; bool eof = false; };
+    // last: the latest byte received or response sent (the keep-alive idle timer).  req_start: when the request now in the buffer began -- its first
+    // byte, or the answer to the request before it on the same connection: a per-request DEADLINE, so a client trickling a byte every few seconds
+    // gets its 408 like one that stalls outright.
+    struct Conn { int fd; std::string buf; Clock::time_point last, req_start; bool continued = false; bool eof = false; };
     std::vector<Conn> conns;
     size_t served = 0;
     auto close_at = [&](size_t i) { ::close(conns[i].fd); conns.erase(conns.begin() + (long)i); };
@@ -219,7 +222,7 @@ size_t HttpListener::serve(size_t max_requests) {
             } catch (const std::exception &) {
                 respond(c.fd, 500, "Internal Server Error", "{\"error\":\"handler failed\"}", keep);
             }
-            c.last = Clock::now();
+            c.last = c.req_start = Clock::now();
             if (!keep) return false;
         }
         return true;
@@ -238,7 +241,7 @@ size_t HttpListener::serve(size_t max_requests) {
             if (ev & POLLIN) {
                 char tmp[65536];
                 const ssize_t r = ::recv(c.fd, tmp, sizeof tmp, MSG_DONTWAIT);
-                if (r > 0) { c.buf.append(tmp, (size_t)r); c.last = now; alive = drain(c); }
+                if (r > 0) { if (c.buf.empty()) c.req_start = now; c.buf.append(tmp, (size_t)r); c.last = now; alive = drain(c); }
                 else if (r == 0) alive = false;                              // the peer closed; a partial request dies with it
                 else if (errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR) alive = false;
             } else if (ev & (POLLERR | POLLHUP | POLLNVAL)) {
@@ -246,7 +249,8 @@ size_t HttpListener::serve(size_t max_requests) {
             }
             if (alive) {
                 const auto quiet = std::chrono::duration_cast<std::chrono::milliseconds>(now - c.last).count();
-                if (!c.buf.empty() && quiet > REQUEST_TIMEOUT_MS) { respond(c.fd, 408, "Request Timeout", "{\"error\":\"request not completed in time\"}", false); alive = false; }
+                const auto pending = std::chrono::duration_cast<std::chrono::milliseconds>(now - c.req_start).count();
+                if (!c.buf.empty() && pending > m_RequestTimeoutMs) { respond(c.fd, 408, "Request Timeout", "{\"error\":\"request not completed in time\"}", false); alive = false; }
                 else if (c.buf.empty() && quiet > IDLE_TIMEOUT_MS) alive = false;
             }
             if (!alive) close_at(i);
@@ -261,7 +265,7 @@ size_t HttpListener::serve(size_t max_requests) {
                 // the kernel gives up on a blocked send after SEND_TIMEOUT_S, send_all() fails, the connection is closed
                 timeval tv{SEND_TIMEOUT_S, 0};
                 ::setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
-                conns.push_back(Conn{c, std::string(), Clock::now()});
+                conns.push_back(Conn{c, std::string(), Clock::now(), Clock::now()});
             }
         }
     }

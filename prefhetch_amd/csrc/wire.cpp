@@ -411,10 +411,9 @@ std::string handle_pir_layout(const Server &server) {
 static void check_residues(const uint64_t *w, size_t n_limb_polys, uint32_t limbs_cycle, const char *what) {
     constexpr size_t N = Server::ENC_RING_DEGREE;
     // key layout [..][K = L + 1][N] cycles over L data primes + the special prime; ciphertext layout cycles over the L data primes
-    static constexpr uint64_t SPECIAL = 0xFFFFFEBC001ull;                  // SEAL BFVDefault(8192): the fifth prime
     for (size_t p = 0; p < n_limb_polys; ++p) {
         const uint32_t l = (uint32_t)(p % limbs_cycle);
-        const uint64_t q = l < Server::ENC_LIMBS ? Server::ENC_MODULI[l] : SPECIAL;
+        const uint64_t q = l < Server::ENC_LIMBS ? Server::ENC_MODULI[l] : Server::ENC_SPECIAL_PRIME;
         for (size_t i = 0; i < N; ++i)
             if (w[p * N + i] >= q) throw std::out_of_range(std::string(what) + ": residue out of range (limb " + std::to_string(l) + ")");
     }
@@ -423,7 +422,8 @@ static void check_residues(const uint64_t *w, size_t n_limb_polys, uint32_t limb
 std::string handle_precise_vector_pir_private(const Server &server, const std::string &body) {
     // The Galois keys of the expansion (tens of megabytes) are sent once per SESSION and kept for the requests that follow without
     // "galoisKeys".  A client names its session with the optional string "session" (the reference's single-client demo sends
-    // none: session ""), so one client's keys never replace another's; at most MAX_SESSIONS key sets are kept (oldest dropped).
+    // none: session ""), so one client's keys never replace another's; at most MAX_SESSIONS key sets are kept, the least recently USED one
+    // dropped.  Session ids are not authenticated: whoever names a session may replace its keys (as anyone may call any route of the reference).
     static std::mutex key_lock;
     static std::vector<std::pair<std::string, std::vector<uint64_t>>> sessions;
     constexpr size_t MAX_SESSIONS = 8;
@@ -462,6 +462,7 @@ std::string handle_precise_vector_pir_private(const Server &server, const std::s
         }
         if (it == sessions.end() || it->second.size() != key_words)
             throw std::out_of_range("precise-vector-pir-private: no Galois keys in this request and none kept for this session");
+        if (it + 1 != sessions.end()) { std::rotate(it, it + 1, sessions.end()); it = sessions.end() - 1; }      // most recently used last
         keys = it->second;
     }
     const Json &blob = req.at("queryCiphertexts");

@@ -166,6 +166,11 @@ int main() {
 
         // client: t must exceed twice the largest inner product, 128 * 255^2 = 8 323 200
         const uint64_t t = (1ull << 25) + 0x8001;
+        {   // the server's parameter set and the client's table name the same primes (the wire format checks key residues against the server's)
+            const bfv::Params pp = bfv::Params::seal_default(Server::ENC_RING_DEGREE, t);
+            EXPECT(pp.special_prime == Server::ENC_SPECIAL_PRIME && pp.moduli.size() == Server::ENC_LIMBS);
+            for (size_t l = 0; l < pp.moduli.size() && l < Server::ENC_LIMBS; ++l) EXPECT(pp.moduli[l] == Server::ENC_MODULI[l]);
+        }
         bfv::Context ctx(bfv::Params::seal_default(Server::ENC_RING_DEGREE, t));
         bfv::KeyGenerator keygen(ctx, bfv::seeded_random(42));
         bfv::PublicKey pk = keygen.create_public_key();

@@ -181,7 +181,7 @@ static int recall(const char *path) {
 // HTTP listener without a Server behind it: prints "PORT <n>", answers `n_requests` requests, exits.  Routes: GET /query
 // -> a tiny centroid array; POST /echo -> the request body; POST /boom -> the handler throws (500); POST /badbody -> a
 // std::out_of_range that is not a routing failure (500); anything else -> "no such route" (404).
-static int http(size_t n_requests) {
+static int http(size_t n_requests, int request_timeout_ms = 0) {
     wire::HttpListener listener([](const std::string &method, const std::string &route, const std::string &body) -> std::string {
         if (route == "query" && method == "GET") return "[[1.5,2.0]]";
         if (route == "echo") return body;
@@ -189,6 +189,7 @@ static int http(size_t n_requests) {
         if (route == "badbody") throw std::out_of_range("key 'preciseQuery' not found");
         throw std::out_of_range("no such route: " + route);
     }, "127.0.0.1", 0, 8u << 20);
+    if (request_timeout_ms > 0) listener.set_request_timeout_ms(request_timeout_ms);
     std::printf("PORT %u\n", (unsigned)listener.port());
     std::fflush(stdout);
     const size_t served = listener.serve(n_requests);
@@ -224,9 +225,9 @@ static int http_loopback() {
 
 int main(int argc, char **argv) {
     if (argc >= 2 && std::strcmp(argv[1], "selftest") == 0) return selftest();
-    if (argc >= 3 && std::strcmp(argv[1], "http") == 0) return http((size_t)std::atoll(argv[2]));
+    if (argc >= 3 && std::strcmp(argv[1], "http") == 0) return http((size_t)std::atoll(argv[2]), argc >= 4 ? std::atoi(argv[3]) : 0);
     if (argc >= 2 && std::strcmp(argv[1], "http-loopback") == 0) return http_loopback();
     if (argc >= 3 && std::strcmp(argv[1], "recall") == 0) return recall(argv[2]);
-    std::printf("usage: test_wire selftest | recall <file> | http <n requests> | http-loopback\n");
+    std::printf("usage: test_wire selftest | recall <file> | http <n requests> [request timeout ms] | http-loopback\n");
     return 2;
 }

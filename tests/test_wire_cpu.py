@@ -178,3 +178,53 @@ def test_http_listener_is_not_blocked_by_idle_or_stalled_clients():
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def test_http_request_deadline_is_per_request_not_per_byte():
+    """a client that trickles one byte at a time (never idle for long) must still get its 408 once the REQUEST is older than the
+    timeout -- an inter-byte idle timer would let 256 such clients hold every connection slot.  Listener with a 1.5 s request timeout; the
+    trickler sends a byte every 0.2 s.  Meanwhile a well-behaved client is served, and a keep-alive connection that waits LONGER than the
+    request timeout between two complete requests is not punished for it (the deadline runs from a request's first byte)."""
+    import http.client
+    import socket
+    import time
+    p = subprocess.Popen([BIN, "http", "3", "1500"], stdout=subprocess.PIPE, text=True)
+    try:
+        port = int(p.stdout.readline().split()[1])
+        keep = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
+        keep.request("POST", "/echo", body="one")                          # request 1
+        assert keep.getresponse().read() == b"one"
+        s_ = socket.create_connection(("127.0.0.1", port))
+        head = b"POST /echo HTTP/1.1\r\nHost: x\r\nContent-Length: 400\r\n\r\n"
+        s_.sendall(head)
+        s_.settimeout(0.01)
+        t0, resp = time.time(), b""
+        while time.time() - t0 < 6.0 and b"\r\n\r\n" not in resp:
+            try:
+                s_.sendall(b"x")
+            except OSError:
+                break
+            try:
+                got = s_.recv(4096)
+                if not got:
+                    break
+                resp += got
+            except socket.timeout:
+                pass
+            time.sleep(0.2)
+        waited = time.time() - t0
+        assert resp.startswith(b"HTTP/1.1 408"), resp[:60]
+        assert 1.2 < waited < 3.5, waited
+        c = http.client.HTTPConnection("127.0.0.1", port, timeout=10)
+        c.request("POST", "/echo", body="hello")                           # request 2
+        assert c.getresponse().read() == b"hello"
+        time.sleep(0.5)                                                    # (the keep-alive connection has now idled > 1.5 s since request 1)
+        keep.request("POST", "/echo", body="two")                          # request 3
+        r = keep.getresponse()
+        assert r.status == 200 and r.read() == b"two"
+        out, _ = p.communicate(timeout=30)
+        assert "served 3" in out
+        s_.close()
+    finally:
+        if p.poll() is None:
+            p.kill()
