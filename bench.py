@@ -170,15 +170,29 @@ def cpu_baseline(threads, ct, pt, xb, xq):
 
 
 def verify_outputs(out, D, I, h_ct, h_pt, h_xb, h_xq):
-    """The buffers the timed steps wrote, checked against the oracle after the timed region: ciphertexts 0..1 bit for bit,
-    (D, I) of queries 0..3 bit for bit (integer-valued data: every fp32 distance is exact)."""
+    """The buffers the timed steps wrote, checked against the oracle after the timed region: ciphertexts 0, 1, the middle one and the last bit
+    for bit; (D, I) of eight queries spread over the query tiles bit for bit (integer-valued data: every fp32 distance is exact); and for EVERY
+    query of the batch that its distances are those of the rows it names, in (distance, id) order."""
+    import numpy as np
     import oracle
     import prefhetch_amd as pf
-    exp = oracle.Oracle(N_RING, MODULI).ct_pt_mul(h_ct[:2], h_pt[:2])
-    ok_ct = bool((pf.to_host_u64(out[:2]) == exp).all())
-    Dr, Ir = oracle.flat_l2_search(h_xb, h_xq[:4], TOPK)
-    ok_flat = bool((I[:4].cpu().numpy() == Ir).all() and (D[:4].cpu().numpy() == Dr).all())
-    return ok_ct and ok_flat, {"ct_x_pt_first_2_bit_exact": ok_ct, "prefilter_first_4_bit_exact": ok_flat}
+    nct = int(out.shape[0])
+    cts = sorted({i for i in (0, 1, nct // 2, nct - 1) if 0 <= i < nct})
+    exp = oracle.Oracle(N_RING, MODULI).ct_pt_mul(h_ct[cts], h_pt[cts])
+    ok_ct = bool((pf.to_host_u64(out[cts]) == exp).all())
+    Dn, In = D.cpu().numpy(), I.cpu().numpy()
+    nqv = len(Dn)                                                       # (multi-GPU: the first rows of the gathered block)
+    qs = sorted({i for i in (0, 1, 2, 3, 129, nqv // 2, 777, nqv - 1) if 0 <= i < nqv})
+    Dr, Ir = oracle.flat_l2_search(h_xb, h_xq[qs], TOPK)
+    ok_flat = bool((In[qs] == Ir).all() and (Dn[qs] == Dr).all())
+    ok_all = True
+    for q0 in range(0, nqv, 128):
+        rows = h_xb[In[q0:q0 + 128]].astype(np.float64)                 # [<=128][k][d]
+        dd = ((rows - h_xq[q0:q0 + 128, None, :].astype(np.float64)) ** 2).sum(axis=2)
+        ok_all = ok_all and bool((dd == Dn[q0:q0 + 128].astype(np.float64)).all())
+    ok_all = ok_all and bool(((Dn[:, 1:] > Dn[:, :-1]) | ((Dn[:, 1:] == Dn[:, :-1]) & (In[:, 1:] > In[:, :-1]))).all())
+    return ok_ct and ok_flat and ok_all, {"ct_x_pt_%d_ciphertexts_bit_exact" % len(cts): ok_ct, "prefilter_%d_queries_bit_exact_vs_oracle" % len(qs): ok_flat,
+                                          "prefilter_all_%d_queries_distances_match_their_rows_and_are_ordered" % nqv: ok_all}
 
 
 def roofline_block(B, ms_b, sustained_ms=None):
