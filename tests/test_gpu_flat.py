@@ -672,7 +672,7 @@ def test_slab_tiles_worst_case_rounding_and_nonfinite_queries():
     import prefhetch_amd as pf
     rng = np.random.default_rng(29)
     d, nb, nq, k = 512, 24000, 140, 10
-    mag = np.float32(3.0) * np.float32(1.0 + 2.0 ** -8)
+    mag = np.float32(4.0) * np.float32(1.0 + 2.0 ** -8)      # 4 + half a bf16 ulp: exactly halfway, ties-to-even rounds it down
     xb = (rng.integers(0, 2, (nb, d)) * 2 - 1).astype(np.float32) * mag
     xq = xb[rng.integers(8192, nb, nq)].copy()
     flip = rng.integers(0, d, (nq, 3))
@@ -702,7 +702,7 @@ def test_bf16_filter_worst_case_rounding(d):
     import prefhetch_amd as pf
     rng = np.random.default_rng(23)
     nb, nq, k = 30000, 160, 10
-    mag = np.float32(3.0) * np.float32(1.0 + 2.0 ** -8)
+    mag = np.float32(4.0) * np.float32(1.0 + 2.0 ** -8)      # 4 + half a bf16 ulp: exactly halfway, ties-to-even rounds it down
     xb = (rng.integers(0, 2, (nb, d)) * 2 - 1).astype(np.float32) * mag
     xq = (rng.integers(0, 2, (nq, d)) * 2 - 1).astype(np.float32) * mag
     picks = rng.integers(8192, nb, 100)                                # rows behind the bootstrap chunk: only the filter can find them
