@@ -665,6 +665,48 @@ def test_rows_longer_than_256_take_the_slab_tiles(d, law):
             np.testing.assert_allclose(D1[:3].cpu().numpy(), Dr, rtol=RTOL if d <= 512 else 1e-4)
 
 
+def test_rows_longer_than_256_edge_shapes_and_graph_capture():
+    """[r4] the slab-tile path at its edges: a base shorter than the bootstrap chunk and one of a single row (no filtered chunk ever runs), batches
+    of 1 / 64 / 65 queries (the path starts at 65), k = 1 and k = 1024 (many small chunks), a row length that is not a multiple of 4 (the fix-up's
+    scalar chain); and, after pf_flat_reserve, a search captured into a hipGraph and replayed on fresh queries -- every result equal to the
+    fp32-operand tiles' bit for bit."""
+    import prefhetch_amd as pf
+    dev = _dev()
+    rng = np.random.default_rng(41)
+    for d, nb, nq, k in ((300, 1, 70, 1), (300, 5000, 70, 7), (515, 20000, 1, 10), (515, 20000, 64, 10), (515, 20000, 65, 10), (384, 30000, 130, 1), (384, 30000, 130, 1024)):
+        xb = rng.standard_normal((nb, d)).astype(np.float32)
+        xq = rng.standard_normal((nq, d)).astype(np.float32)
+        f = pf.FlatL2(xb, dev)
+        q = torch.from_numpy(xq).to(dev)
+        D1, I1 = f.search(q, k)
+        f.operands16(0)
+        D0, I0 = f.search(q, k)
+        assert (I1 == I0).all() and (D1.view(torch.int32) == D0.view(torch.int32)).all(), (d, nb, nq, k)
+    d, nb, nq, k = 512, 40000, 200, 20
+    xb = rng.standard_normal((nb, d)).astype(np.float32)
+    f = pf.FlatL2(xb, dev)
+    f.reserve(nq, k)
+    xq = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    xq.copy_(torch.from_numpy(rng.standard_normal((nq, d)).astype(np.float32)))
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        f.search(xq, k)                                               # warm-up outside capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        D, I = f.search(xq, k)
+    for _ in range(2):
+        hq = rng.standard_normal((nq, d)).astype(np.float32)
+        xq.copy_(torch.from_numpy(hq))
+        g.replay()
+        torch.cuda.synchronize()
+        Dg, Ig = D.clone(), I.clone()
+        f.operands16(0)
+        D0, I0 = f.search(torch.from_numpy(hq).to(dev), k)
+        f.operands16(1)
+        assert (Ig == I0).all() and (Dg.view(torch.int32) == D0.view(torch.int32)).all()
+
+
 def test_slab_tiles_worst_case_rounding_and_nonfinite_queries():
     """d = 512: every coordinate +-(1 + 2^-8) c (halfway between two bf16 values: every product loses the full rounding), queries copies of base rows
     behind the bootstrap chunk -- the margin of the slab tiles' filter met with equality; and a batch with NaN / Inf / 1e30 inside some queries:
