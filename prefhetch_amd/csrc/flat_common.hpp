@@ -91,7 +91,7 @@ struct TileArgs {
     const int8_t *xq8; const int8_t *xb8;
     uint32_t base_exact;    // every value of the base is exactly representable in bf16
     float bn_max;           // largest |y|^2 of the base (the inexact path's filter margin)
-    uint32_t i8_old;        // experiment knob (PF_FLAT_I8_OLD, read at index creation): the round-3 int8 walk (tile16_walk<.., I8>) instead of tile8_walk
+    uint32_t i8_old;        // the LDS-tiled int8 walk (tile16_walk<.., I8>) instead of the streamed one (tile8_walk): batches of one or two query tiles (pf_flat.hip), or PF_FLAT_I8_OLD
     // the streamed int8 walk (flat_tile8.hpp): the base in fragment order, its columns' threshold halves, the queries' sum (x - 128)
     const int8_t *xb8f; const int *c0f; const int *qsx8;
     uint32_t only_flagged;  // k_l2_tile beside the slab tiles (flat_wide16.hpp): only the query tiles whose word has bit 1 set

@@ -79,7 +79,10 @@ __device__ unsigned long long pf_flat_flush_stamp_buf[PF_FS_WGS * 4 * 8 * 8];   
 // non-zero word as the tile ends -- a ballot and an LDS write, no barrier -- and calls this only when a ring is nearly full or the walk ends:
 // the parking above cost a quarter of the int8 walk's time); rc records, ct_base = the walk's first tile.
 // LAST: this instantiation is only ever the walk's last flush (compiled with the slab-wise evaluation of inexact survivors)
-template <int D, int MT, int NJ, int TN, bool I8 = false, bool RING = false, bool LAST = false>
+// PADDED: the image rows are the data's rows padded with zeros (p.d < D): the fp32 rows the inexact survivors are evaluated on then have a run-time
+// length.  A separate instantiation: with the run-time forms merely present beside the compile-time ones, the N(0,1) search at d = 128 lost 8 %
+// (0.64 -> 0.69 ms: more code and registers in a kernel at its limits).
+template <int D, int MT, int NJ, int TN, bool I8 = false, bool RING = false, bool LAST = false, bool PADDED = false>
 __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, const float *sA, size_t q0, int tid, uint32_t (&surv)[MT][NJ],
                                              uint32_t ct_base, int wm, int wn, bool approx, char *xstage, uint32_t q_valid, bool final,
                                              uint32_t flush_no = 0, const uint2 *ring = nullptr, uint32_t rc = 0) {
@@ -227,8 +230,8 @@ __device__ PF_FLUSH_INLINE void pend16_flush(const TileArgs &p, Pend16 &pd, cons
             const uint32_t XROWS = final ? X_ALL : X_ONE;
             // (the fp32 rows have p.d values; D is the images' row length, p.d padded with zeros.  Rows whose length is not a multiple of 4 are not
             // 16-byte aligned: they are read value by value.)
-            const uint32_t dv = p.d;
-            const bool vec4 = (dv & 3u) == 0;
+            const uint32_t dv = PADDED ? p.d : (uint32_t)D;
+            const bool vec4 = !PADDED || (dv & 3u) == 0;
             if (tid < 128) {
                 const uint32_t c = pd.rcnt[tid];
                 pd.rbase[tid] = c ? atomicAdd(&p.cand_cnt[q0 + tid], c) : 0u;

@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x16 tile_mma(const bf16x8 a, const bf16x8 b, const
 // the depth, 16 instead of 36 of them per tile at d = 128, half the bytes copied into and read from LDS.  The accumulators start at the
 // (row + column) halves of the threshold instead of zero (what the ninth k-step does for bf16) and are exact integers.
 constexpr int AUX8 = 16;                        // bytes a base row of the int8 image carries behind its d values: c0 (int32), 12 spare
-template <bool FILTER, int D, bool I8>                              // D = row length (a multiple of 16 up to 256): every loop below is compile-time
+template <bool FILTER, int D, bool I8, bool PADDED = false>         // D = row length (a multiple of 16 up to 256): every loop below is compile-time; PADDED: p.d < D (flat_flush16.hpp)
 __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t group, const uint32_t n_groups, char *smem, float *stage, Pend16 &pend,
                                             const uint32_t qt, const uint32_t grp, const uint32_t qflags) {
     using GEO = typename Geo16Of<D>::type;
@@ -71,8 +71,10 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
     const bool approx = !I8 && (!p.base_exact || (qflags & 1u));    // (qflags: workgroup-uniform; the caller picked I8 for exact 8-bit operands only)
     if (!I8 && ((!FILTER && approx) || (FILTER && (qflags & 2u)))) {
         for (uint32_t ct = ct0; ct < ct1; ++ct) {
-            if (p.d % TK == 0) l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);        // workgroup-uniform (a padded row length has the bounds-checked slab fetch)
-            else l2_tile_f32<FILTER, GEO, false, false>(p, smem, qt, ct);
+            if constexpr (PADDED) {
+                if (p.d % TK == 0) l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);    // workgroup-uniform (a padded row length has the bounds-checked slab fetch)
+                else l2_tile_f32<FILTER, GEO, false, false>(p, smem, qt, ct);
+            } else l2_tile_f32<FILTER, GEO, true, false>(p, smem, qt, ct);
             __syncthreads();
         }
         return;
@@ -389,7 +391,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #else
                 constexpr bool abl_exact = false;
 #endif
-                pend16_flush<D, MT, NJ, TN, I8, false, false>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, buf_cur, q_valid, false, (ct - ct0) / MT);
+                pend16_flush<D, MT, NJ, TN, I8, false, false, PADDED>(p, pend, stage, q0, tid, surv, ct - u, wm, wn, approx && !abl_exact, buf_cur, q_valid, false, (ct - ct0) / MT);
 #pragma unroll
                 for (int e = 0; e < MT * NJ; ++e) sv[e] = 0;
             }
@@ -406,7 +408,7 @@ __device__ __forceinline__ void tile16_walk(const TileArgs &p, const uint32_t gr
 #else
             constexpr bool abl_exact2 = false;
 #endif
-            pend16_flush<D, MT, NJ, TN, I8, false, true>(p, pend, stage, q0, tid, surv, ct1 - 1 - u_last, wm, wn, approx && !abl_exact2, smem, q_valid, true, (ct1 - 1 - ct0) / MT);
+            pend16_flush<D, MT, NJ, TN, I8, false, true, PADDED>(p, pend, stage, q0, tid, surv, ct1 - 1 - u_last, wm, wn, approx && !abl_exact2, smem, q_valid, true, (ct1 - 1 - ct0) / MT);
         }
     }
 }
@@ -419,7 +421,7 @@ __device__ __forceinline__ void tile8_walk(const TileArgs &p, const uint32_t gro
 // WITH8: the instantiation that carries the streamed int8 walk (8-bit bases).  Bases that are not 8-bit launch the one without it: the walk's mere
 // presence in the kernel changes the code hipcc builds for the bf16 loop (an s_waitcnt vmcnt(0) behind the tile's first copy request: +8 % on the
 // long chunk of an N(0,1) search).
-template <bool FILTER, int D, bool WITH8 = false>
+template <bool FILTER, int D, bool WITH8 = false, bool PADDED = false>
 __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileArgs p, uint32_t group, uint32_t n_groups) {
     using GEO = typename Geo16Of<D>::type;
     constexpr int TM = GEO::TM, TN = GEO::TN, PITCH = (D + (int)AUX16) * 2;
@@ -439,14 +441,14 @@ __global__ void __launch_bounds__(256, Geo16Of<D>::WG_PER_CU) k_l2_tile16(TileAr
             if constexpr (WITH8) {
                 if (!p.i8_old) { tile8_walk<D, SMEM>(p, group, smem, stage, pend, qt, grp); return; }
             }
-            tile16_walk<FILTER, D, true>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
+            tile16_walk<FILTER, D, true, PADDED>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
             return;
         }
     }
 #ifdef PF_ABL_I8ONLY   // experiment (register count of the int8 walk on its own; other query tiles are not processed: wrong results for them)
     if constexpr (!(D % 32 == 0 && D <= 128))
 #endif
-    tile16_walk<FILTER, D, false>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
+    tile16_walk<FILTER, D, false, PADDED>(p, group, n_groups, smem, stage, pend, qt, grp, qflags);
 }
 
 }  // namespace pf

@@ -117,6 +117,7 @@ struct pf_flat {
 
 namespace {
 
+constexpr size_t STREAMED_WALK_MIN_NQ = 256;      // batches up to this size take the LDS-tiled int8 walk (pf_flat_search_packed)
 #ifndef PF_WIDE_GROWTH_DIV
 #define PF_WIDE_GROWTH_DIV 5.0
 #endif
@@ -389,7 +390,11 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
     if (wide) hipLaunchKernelGGL(k_rows_bf16, dim3((unsigned)((nq * (size_t)(f->dpw / 8) + 255) / 256)), dim3(256), 0, s, xq, nq, f->d, q16, f->dpw, qbad, 128u);
     TileArgs t{};
     t.xq16 = q16; t.xb16 = f->xb16; t.q_inexact = qbad; t.base_exact = (wide ? f->exactw : f->exact16) ? 1u : 0u; t.bn_max = f->bn_max;
-    t.xq8 = b8 ? q8 : nullptr; t.xb8 = b8 ? f->xb8 : nullptr; t.i8_old = (f->i8_old || !f->xb8f) ? 1u : 0u;
+    // The streamed int8 walk wants at least three query tiles: every 1 KiB piece of the base is then asked for by three or more waves at about the
+    // same time and all but the first find it in L2.  Below (one or two tiles) a wave's walk is a string of trips to memory, and the LDS-tiled walk
+    // (tile16_walk<.., I8>), which shares a column tile among its four waves, is up to 1.7x faster -- 1M x 128, k = 200, streamed | LDS-tiled:
+    // 64 queries 0.286 | 0.182 ms, 256 0.315 | 0.201, 384 0.245 | 0.263, 512 0.227 | 0.232, 1024 0.335 | 0.354.
+    t.xq8 = b8 ? q8 : nullptr; t.xb8 = b8 ? f->xb8 : nullptr; t.i8_old = (f->i8_old || !f->xb8f || nq <= STREAMED_WALK_MIN_NQ) ? 1u : 0u;
     t.xb8f = f->xb8f; t.c0f = f->c0f; t.qsx8 = qsx;
     t.xq = xq; t.xb = f->xb; t.qn = qn; t.bn = f->bn; t.slab = slab; t.nq = (uint32_t)nq; t.d = f->d; t.slab_ld = (uint32_t)w.slab_ld;
     t.tau = tau; t.cand_cnt = ccnt; t.cand = cand; t.cap = (uint32_t)w.cap;
@@ -420,10 +425,12 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
             const dim3 grid16((unsigned)(((n_groups + 7) / 8) * 8 * t.n_qtiles));
             const uint32_t g32 = (uint32_t)group, n32 = (uint32_t)n_groups;
             switch (dp) {
-#define PF_T16(DD) case DD: if (filter && DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128 && b8 && !t.i8_old) \
-                                hipLaunchKernelGGL((k_l2_tile16<true, DD, (DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128)>), grid16, dim3(256), 0, s, t, g32, n32); \
-                            else if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD>), grid16, dim3(256), 0, s, t, g32, n32); \
-                            else hipLaunchKernelGGL((k_l2_tile16<false, DD>), grid16, dim3(256), 0, s, t, g32, n32); break;
+#define PF_T16P(DD, PAD) do { if (filter && DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128 && b8 && !t.i8_old) \
+                                hipLaunchKernelGGL((k_l2_tile16<true, DD, (DD % 32 == 0 && DD <= 128 && PF_B16_TN == 128), PAD>), grid16, dim3(256), 0, s, t, g32, n32); \
+                            else if (filter) hipLaunchKernelGGL((k_l2_tile16<true, DD, false, PAD>), grid16, dim3(256), 0, s, t, g32, n32); \
+                            else hipLaunchKernelGGL((k_l2_tile16<false, DD, false, PAD>), grid16, dim3(256), 0, s, t, g32, n32); } while (0)
+            // (rows padded to the image's length take their own instantiation: flat_flush16.hpp, PADDED)
+#define PF_T16(DD) case DD: if (dp != f->d) PF_T16P(DD, true); else PF_T16P(DD, false); break;
 #ifdef PF_DEV_ONLY_D128   // development builds (compile time, ISA inspection): rows of 128 values only -- other row lengths are NOT searched (experiment switch)
                 PF_T16(128)
 #else
@@ -431,6 +438,7 @@ pf_status pf_flat_search_packed(pf_flat *f, const float *xq, size_t nq, uint32_t
                 PF_T16(144) PF_T16(160) PF_T16(176) PF_T16(192) PF_T16(208) PF_T16(224) PF_T16(240) PF_T16(256)
 #endif
 #undef PF_T16
+#undef PF_T16P
                 default: break;                                       // (pf_flat_create keeps an image for these row lengths only)
             }
             return;
