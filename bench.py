@@ -187,9 +187,10 @@ def verify_outputs(out, D, I, h_ct, h_pt, h_xb, h_xq):
     ok_flat = bool((In[qs] == Ir).all() and (Dn[qs] == Dr).all())
     ok_all = True
     for q0 in range(0, nqv, 128):
-        rows = h_xb[In[q0:q0 + 128]].astype(np.float64)                 # [<=128][k][d]
-        dd = ((rows - h_xq[q0:q0 + 128, None, :].astype(np.float64)) ** 2).sum(axis=2)
-        ok_all = ok_all and bool((dd == Dn[q0:q0 + 128].astype(np.float64)).all())
+        q1 = min(q0 + 128, nqv)
+        rows = h_xb[In[q0:q1]].astype(np.float64)                       # [<=128][k][d]
+        dd = ((rows - h_xq[q0:q1, None, :].astype(np.float64)) ** 2).sum(axis=2)
+        ok_all = ok_all and bool((dd == Dn[q0:q1].astype(np.float64)).all())
     ok_all = ok_all and bool(((Dn[:, 1:] > Dn[:, :-1]) | ((Dn[:, 1:] == Dn[:, :-1]) & (In[:, 1:] > In[:, :-1]))).all())
     return ok_ct and ok_flat and ok_all, {"ct_x_pt_%d_ciphertexts_bit_exact" % len(cts): ok_ct, "prefilter_%d_queries_bit_exact_vs_oracle" % len(qs): ok_flat,
                                           "prefilter_all_%d_queries_distances_match_their_rows_and_are_ordered" % nqv: ok_all}
