@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
     if (lane < rows) {
         const float *row = tile + lane * (d + 1);
         float acc = 0.f;
-        for (uint32_t k = 0; k < d; ++k) acc = fmaf(row[k], row[k], acc);
+        int sum8 = -128 * (int)(dp - d);                             // sum (value - 128) over the image row, its zero padding included (8-bit data: read below)
+#pragma unroll 8                                                       // (the LDS reads of eight steps in flight ahead of the serial chain)
+        for (uint32_t k = 0; k < d; ++k) { acc = fmaf(row[k], row[k], acc); sum8 += (int)row[k] - 128; }
         norms[r0 + lane] = acc;
         if (x16 && aux) {
             uint32_t b[3];
@@ -86,8 +88,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             *reinterpret_cast<u32x4 *>(x16 + (r0 + lane) * pitch16 + dp) = w;       // 16-byte aligned: dp and pitch16 are multiples of 8
         }
         if (x8 && aux) {                                         // the column's half of the integer threshold (tile16_walk): c0 = -floor(C / 2), C = |y|^2 - 256 sum (y - 128)
-            int sy = -128 * (int)(dp - d);                           // (the padding: value 0 = -128)
-            for (uint32_t k = 0; k < d; ++k) sy += (int)row[k] - 128;
+            const int sy = sum8;
             const int Cc = (int)acc - 256 * sy;
             u32x4 w;
             w[0] = (uint32_t)(-(Cc >> 1)); w[1] = (uint32_t)sy; w[2] = 0; w[3] = 0;      // (sum y' for the unfiltered launch, which forms distances)
@@ -95,9 +96,7 @@ __global__ void __launch_bounds__(64) k_rows_prep(const float *__restrict__ x, s
             if (c0f) c0f[frag8_c0_index(r0 + lane)] = Cc;                               // C itself: the walk halves it, the flush forms distances with it
         }
         if (x8 && !aux && sx8) {                                 // queries: sum (x - 128), the row half of the integer threshold needs it (tile8_walk)
-            int s = -128 * (int)(dp - d);
-            for (uint32_t k = 0; k < d; ++k) s += (int)row[k] - 128;
-            sx8[r0 + lane] = s;
+            sx8[r0 + lane] = sum8;
         }
     }
 }
