@@ -485,11 +485,12 @@ def test_int8_tiles_only_where_both_sides_are_8bit():
     assert (I8[rows].cpu().numpy() == Ir).all() and (D8[rows].cpu().numpy() == Dr).all()
 
 
-def test_int8_tiles_dense_survivors_and_overflow():
+@pytest.mark.parametrize("nq", [200, 300])                            # the LDS-tiled int8 walk (batches up to 256 queries) and the streamed one
+def test_int8_tiles_dense_survivors_and_overflow(nq):
     """base rows ordered by DEcreasing distance to every query (every streamed row passes the integer threshold: lists overflow into the exact rescan,
     flushes in mid-walk), and thresholds at both ends of the int32 range of the row half"""
     import prefhetch_amd as pf
-    nb, nq, k, d = 40000, 200, 100, 128
+    nb, k, d = 40000, 100, 128
     m = (np.arange(nb)[::-1] * (d + 1) // nb)
     xb = (np.arange(d)[None, :] < m[:, None]).astype(np.float32) * 255.0
     rng = np.random.default_rng(5)
@@ -596,15 +597,16 @@ def test_bf16_tiles_edge_shapes(nb, nq, k, d, law):
         assert (I1[:3].cpu().numpy() == Ir).all() and (D1[:3].cpu().numpy() == Dr).all()
 
 
+@pytest.mark.parametrize("nq", [130, 300])                            # (8-bit data: the LDS-tiled int8 walk up to 256 queries, the streamed one above)
 @pytest.mark.parametrize("d", [30, 100, 130, 200, 250])
 @pytest.mark.parametrize("law", ["u8", "int", "gauss", "mixed"])
-def test_padded_row_lengths_take_the_tile_path(d, law):
+def test_padded_row_lengths_take_the_tile_path(d, law, nq):
     """[r4] row lengths that are not whole k-steps of the matrix instructions (any d up to 256): the operand images are padded with zeros and the
     tile paths run -- int8 tiles on 8-bit data (d <= 128), bf16 tiles exact on integers / as a filter otherwise -- bit-identical to the
     fp32-operand tiles and, on integer data, to the oracle.  Batches large enough for filtered chunks behind the bootstrap."""
     import prefhetch_amd as pf
     rng = np.random.default_rng(1000 * d + len(law))
-    nb, nq, k = 21000, 130, 50
+    nb, k = 21000, 50
     if law == "u8":
         xb, xq = rng.integers(0, 256, (nb, d)), rng.integers(0, 256, (nq, d))
     elif law == "int":
