@@ -18,6 +18,10 @@
 //   * Survivors are handled by the wave that found them: verdict words go to a wave-private ring in LDS; when it fills, or the walk ends, the wave
 //     decodes them, reserves its rows' ranges of the candidate lists and evaluates the survivors, 8 lanes per survivor -- while the other wave of the
 //     SIMD keeps the pipes busy.  (Before, a flush stopped the whole workgroup behind three barriers.)
+// What it bought, measured against round 3's library on one lease (EXPERIMENTS.md): the long chunk of a 1024-query search takes what it took (141
+// against 139 us); the gain is the cheaper survivors -- three chunks instead of four, one merge less -- 3.5-5 % of a search.  And it needs readers:
+// with one or two query tiles a piece of the base is asked for by one or two waves and every step is a trip to memory, so batches of up to 256
+// queries keep the LDS-tiled walk (pf_flat.hip: STREAMED_WALK_MIN_NQ), which is up to 1.7x faster there.
 #pragma once
 #ifndef PF_W8_WARM
 #define PF_W8_WARM 0            // steps behind the first whose operands are pulled into L2 while the prologue runs (6: 0.347 -> 0.355 ms per search: off)
